@@ -1,0 +1,117 @@
+/*
+ * oalsfx_hip.h -- C ABI of liboalsfx_hip.so, the MI355X batch backend for the
+ * oalsfxpp effect-process hot path.
+ *
+ * The reference has no FFI: its only seam is C++ (class oalsfxpp::Api, reference
+ * src/oalsfxpp.h:760-922, and the internal EffectState::process virtual,
+ * src/oalsfxpp.cpp:2239-2246).  This ABI is what a binding of that seam needs when
+ * thousands of independent Api instances are advanced together: each call below
+ * names the reference entry point it stands in for.  All handles are opaque, all
+ * buffers are caller-owned plain pointers, no C++ or torch types cross the boundary.
+ *
+ * Conventions (same as the reference): calls return 1 on success and 0 on
+ * failure; oalsfx_batch_error() then returns a static message.  Samples are
+ * interleaved fp32 frames, [instance][frame][channel], and outputs are not clipped.
+ * A batch is not thread-safe; distinct batches are independent.
+ */
+#ifndef OALSFX_HIP_H
+#define OALSFX_HIP_H
+
+#include "oalsfx_desc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oalsfx_batch oalsfx_batch;
+
+/* Mirror of oalsfxpp::Effect (reference src/oalsfxpp.h:532-548): 4-byte type tag followed by
+ * the 108-byte EffectProps union.  sizeof == 112. */
+typedef struct {
+    int32_t type;
+    unsigned char props[108];
+} oalsfx_effect;
+
+/* Mirror of oalsfxpp::SendProps (reference src/oalsfxpp.h:550-581). */
+typedef struct { float gain, gain_hf, gain_lf; } oalsfx_send_props;
+
+/* ---- lifecycle: n_instances x Api::initialize (reference src/oalsfxpp.cpp:3480-3504, 2846-2905).
+ * channel_format is an OALSFX_FMT_* value; device_id is the HIP device ordinal.  Fails (returns
+ * NULL and sets the global message readable through oalsfx_last_error) when the arguments are
+ * out of range or no HIP device is usable -- there is no CPU fallback. */
+oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampling_rate, int effect_count, int device_id);
+void oalsfx_batch_destroy(oalsfx_batch* b);                     /* Api::uninitialize, src/oalsfxpp.cpp:3831 */
+const char* oalsfx_batch_error(const oalsfx_batch* b);          /* Api::get_error_message, src/oalsfxpp.cpp:3836 */
+const char* oalsfx_last_error(void);                            /* message of a failed oalsfx_batch_create */
+
+int oalsfx_batch_instances(const oalsfx_batch* b);
+int oalsfx_batch_channels(const oalsfx_batch* b);               /* Api::get_channel_count, src/oalsfxpp.cpp:3533 */
+int oalsfx_batch_sampling_rate(const oalsfx_batch* b);          /* Api::get_sampling_rate, src/oalsfxpp.cpp:3511 */
+int oalsfx_batch_effect_count(const oalsfx_batch* b);           /* Api::get_effect_count, src/oalsfxpp.cpp:3544 */
+
+/* ---- deferred property setters for the instance range [first, first+count).
+ * `stride_bytes` is the distance between consecutive per-instance records at `effects` /
+ * `props`; 0 broadcasts one record to the whole range. */
+/* Api::set_effect (src/oalsfxpp.cpp:3639-3658; this ABI reports success as 1, the C++ facade keeps
+ * the reference's quirk of returning false). */
+int oalsfx_batch_set_effect(oalsfx_batch* b, int first, int count, int slot, const oalsfx_effect* effects, int stride_bytes);
+/* Api::set_effect_type (src/oalsfxpp.cpp:3597-3616): type tag + that type's default properties. */
+int oalsfx_batch_set_effect_type(oalsfx_batch* b, int first, int count, int slot, int effect_type);
+/* Api::set_effect_props (src/oalsfxpp.cpp:3618-3637): replaces the 108-byte union only. */
+int oalsfx_batch_set_effect_props(oalsfx_batch* b, int first, int count, int slot, const void* props, int stride_bytes);
+/* Api::set_send_props (src/oalsfxpp.cpp:3712-3736); slot < 0 addresses the direct send. */
+int oalsfx_batch_set_send_props(oalsfx_batch* b, int first, int count, int slot, const oalsfx_send_props* props);
+/* Api::get_effect / get_deferred_effect (src/oalsfxpp.cpp:3555-3595) for one instance. */
+int oalsfx_batch_get_effect(const oalsfx_batch* b, int instance, int slot, int deferred, oalsfx_effect* out);
+/* Api::get_send_props / get_deferred_send_props (src/oalsfxpp.cpp:3660-3710). */
+int oalsfx_batch_get_send_props(const oalsfx_batch* b, int instance, int slot, int deferred, oalsfx_send_props* out);
+/* Api::apply_changes (src/oalsfxpp.cpp:3738-3783) on every instance of the range. */
+int oalsfx_batch_apply_changes(oalsfx_batch* b, int first, int count);
+
+/* ---- the hot path: Api::mix (src/oalsfxpp.cpp:3785-3829) for every instance at once.
+ * src and dst hold n_instances * frames * channels floats.  frames may be any positive count;
+ * more than 2048 are processed in 2048-frame chunks like the reference.  frames == 0 succeeds. */
+int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host);
+/* Same with buffers already resident in device memory; launches on `hip_stream` (a hipStream_t, or
+ * NULL for the batch's own stream) and returns without synchronising. */
+int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream);
+int oalsfx_batch_synchronize(oalsfx_batch* b);
+/* The batch's own HIP stream (a hipStream_t) so callers can bracket launches with their own events. */
+void* oalsfx_batch_stream(oalsfx_batch* b);
+
+/* ---- state read-back for tests and checkpoints (the reference keeps this in private members of
+ * the EffectState subclasses). */
+int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_params* params, oalsfx_slot_state* state);
+/* Copies up to max_floats of the slot's delay rings; returns the ring size in floats (0: no ring). */
+int oalsfx_batch_read_ring(oalsfx_batch* b, int instance, int slot, float* out, int max_floats);
+int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params* params, oalsfx_source_state* state);
+
+/* ---- synthetic input generator of the benchmark filled directly in device memory:
+ * value(instance, k) for buffer `buffer_index`, identical to the oracle's generator. */
+int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_index, float* dst_dev, void* hip_stream);
+
+/* ---- HIP-event timing of the dominant kernel, measured on the launch stream.  While enabled, every
+ * effect kernel launch is bracketed by events; read() returns the number of launches of `effect_type`
+ * since enable and their summed duration in milliseconds. */
+int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
+int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
+
+/* ---- host-only helpers (no GPU needed): the parameter-update path, exposed so the descriptors can be
+ * checked against the reference and so the CPU oracle can be driven with identical parameters. */
+void oalsfx_host_effect_defaults(int effect_type, oalsfx_effect* out);        /* Effect::set_type_and_defaults */
+void oalsfx_host_effect_normalize(oalsfx_effect* e);                          /* Effect::normalize */
+int oalsfx_host_derive_slot(int channel_format, int sampling_rate, const oalsfx_effect* normalized, oalsfx_slot_params* out);
+int oalsfx_host_derive_source(int channel_format, int sampling_rate, int effect_count, const oalsfx_send_props* direct,
+                              const oalsfx_send_props* aux /* [effect_count] */, const int* slot_types /* [effect_count] */,
+                              oalsfx_source_params* out);
+int oalsfx_host_ring_floats(int effect_type, int sampling_rate);
+int oalsfx_host_channel_count(int channel_format);
+int oalsfx_host_preset_count(void);
+const char* oalsfx_host_preset_name(int index);
+int oalsfx_host_preset(int index, void* reverb_props_out /* 108 bytes */);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* OALSFX_HIP_H */

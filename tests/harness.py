@@ -1,0 +1,148 @@
+"""Shared helpers for the parity tests.
+
+`OracleApi` drives the CPU oracle (oracle/liboracle.so) through the same call sequence a caller
+would use on `oalsfxpp::Api`: deferred setters, apply_changes, mix.  The parameter side goes
+through the *product's* host update path (oalsfx_host_* entry points of liboalsfx_hip.so); the
+sample side is the oracle.  It mirrors the reference's apply/refresh rules
+(Api::apply_changes, reference src/oalsfxpp.cpp:3738-3783; update_context_sources, :3397-3412).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oalsfxpp_amd import desc, lib  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def make_effect(effect_type, **fields):
+    """Default properties of `effect_type` with some fields overridden (un-normalised)."""
+    e = lib.effect_defaults(effect_type)
+    if fields:
+        member = getattr(e.props, desc.PROPS_MEMBER[effect_type])
+        for k, v in fields.items():
+            if isinstance(v, (list, tuple)):
+                arr = getattr(member, k)
+                for i, x in enumerate(v):
+                    arr[i] = x
+            else:
+                setattr(member, k, v)
+    return e
+
+
+def preset_effect(index, effect_type=desc.EAX_REVERB):
+    _, p = lib.preset(index)
+    e = lib.effect_defaults(effect_type)
+    e.props.reverb = p
+    return e
+
+
+def effects_equal(a, b):
+    """Effect::are_equal on normalised effects: compare the live member only."""
+    if a.type != b.type:
+        return False
+    if a.type == desc.NULL:
+        return True
+    m = desc.PROPS_MEMBER[a.type]
+    return bytes(getattr(a.props, m)) == bytes(getattr(b.props, m))
+
+
+class OracleApi:
+    def __init__(self, channel_format, rate, effect_count):
+        self.format, self.rate, self.effect_count = channel_format, rate, effect_count
+        self.channels = desc.FORMAT_CHANNELS[channel_format]
+        self.oracle = orc.Oracle(self.channels, effect_count)
+        null = lib.effect_defaults(desc.NULL)
+        self.deferred = [desc.Effect.from_buffer_copy(bytes(null)) for _ in range(effect_count)]
+        self.active = [desc.Effect.from_buffer_copy(bytes(null)) for _ in range(effect_count)]
+        self.params = [None] * effect_count
+        self.seq = [0] * effect_count
+        self.slot_changed = [True] * effect_count
+        self.slot_restart = [True] * effect_count
+        self.direct = desc.SendProps(1.0, 1.0, 1.0)
+        self.direct_deferred = desc.SendProps(1.0, 1.0, 1.0)
+        self.aux = [desc.SendProps(1.0, 1.0, 1.0) for _ in range(effect_count)]
+        self.source_changed = True
+
+    # ---- deferred setters ----
+    def set_effect(self, slot, effect):
+        self.deferred[slot] = desc.Effect.from_buffer_copy(bytes(effect))
+
+    def set_effect_type(self, slot, effect_type):
+        self.deferred[slot] = lib.effect_defaults(effect_type)
+
+    def set_send_props(self, slot, gain, gain_hf, gain_lf):
+        if slot < 0:
+            self.direct_deferred = desc.SendProps(gain, gain_hf, gain_lf)
+        else:
+            # the reference writes the active aux props directly, un-normalised (src/oalsfxpp.cpp:3728-3733)
+            self.aux[slot] = desc.SendProps(gain, gain_hf, gain_lf)
+
+    def apply_changes(self):
+        for i in range(self.effect_count):
+            self.deferred[i] = lib.effect_normalized(self.deferred[i])
+            if not effects_equal(self.deferred[i], self.active[i]):
+                if self.deferred[i].type != self.active[i].type:
+                    self.slot_restart[i] = True
+                self.active[i] = desc.Effect.from_buffer_copy(bytes(self.deferred[i]))
+                self.slot_changed[i] = True
+        d = self.direct_deferred
+        d = desc.SendProps(min(1.0, max(0.0, d.gain)), min(1.0, max(0.0, d.gain_hf)), min(1.0, max(0.0, d.gain_lf)))
+        self.direct_deferred = d
+        if bytes(d) != bytes(self.direct):
+            self.direct = d
+            self.source_changed = True
+        for a in self.aux:
+            if bytes(a) != bytes(desc.SendProps(1.0, 1.0, 1.0)):
+                self.source_changed = True
+
+    # ---- what mix_data's lazy refresh does ----
+    def refresh(self):
+        updated = False
+        for i in range(self.effect_count):
+            if not self.slot_changed[i]:
+                continue
+            self.slot_changed[i] = False
+            updated = True
+            p = lib.derive_slot(self.format, self.rate, self.active[i])
+            self.seq[i] += 1
+            p.update_seq = self.seq[i]
+            self.params[i] = p
+            self.oracle.set_slot(i, p, self.slot_restart[i])
+            self.slot_restart[i] = False
+        if self.source_changed:
+            self.source_changed = False
+            updated = True
+        if updated:
+            self.source_params = lib.derive_source(self.format, self.rate, self.direct, self.aux, [e.type for e in self.active])
+            self.oracle.set_source(self.source_params)
+
+    def mix(self, src):
+        self.refresh()
+        return self.oracle.mix(src)
+
+
+def noise(seed, frames, channels):
+    """Deterministic uniform [-1, 1) test signal (the benchmark generator)."""
+    return orc.synth(seed, 0, frames * channels).reshape(frames, channels)
+
+
+def struct_diff(a, b, path=""):
+    """Field-by-field differences of two ctypes structures (for readable assertion messages)."""
+    out = []
+    if isinstance(a, (C.Structure, C.Union)):
+        for name, *_ in a._fields_:
+            out += struct_diff(getattr(a, name), getattr(b, name), f"{path}.{name}")
+    elif isinstance(a, C.Array):
+        for i in range(len(a)):
+            out += struct_diff(a[i], b[i], f"{path}[{i}]")
+    else:
+        same = (a == b) or (isinstance(a, float) and np.float32(a).tobytes() == np.float32(b).tobytes())
+        if not same:
+            out.append(f"{path}: {a!r} != {b!r}")
+    return out
