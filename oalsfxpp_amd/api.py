@@ -1,0 +1,218 @@
+"""Python host mirror of the batch C ABI (include/oalsfx_hip.h).
+
+`Batch` advances N independent effect chains with one call; `Api` is the one-instance view with the
+method names of the reference's `oalsfxpp::Api` (reference src/oalsfxpp.h:760-922).  Both are thin:
+every call goes straight to liboalsfx_hip.so, nothing is computed in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import desc, lib
+
+_fp = C.POINTER(C.c_float)
+
+
+class BatchError(RuntimeError):
+    pass
+
+
+class Batch:
+    def __init__(self, n_instances, channel_format=desc.FMT_STEREO, sampling_rate=48000, effect_count=1, device_id=0):
+        self._lib = lib.load()
+        h = self._lib.oalsfx_batch_create(n_instances, channel_format, sampling_rate, effect_count, device_id)
+        if not h:
+            raise BatchError(self._lib.oalsfx_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n = n_instances
+        self.channel_format = channel_format
+        self.rate = sampling_rate
+        self.effect_count = effect_count
+        self.channels = self._lib.oalsfx_batch_channels(self._h)
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.oalsfx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, ok):
+        if not ok:
+            raise BatchError(self._lib.oalsfx_batch_error(self._h).decode())
+
+    @property
+    def error(self):
+        return self._lib.oalsfx_batch_error(self._h).decode()
+
+    # ---- deferred setters (instance range [first, first+count)) ----
+    def _range(self, first, count):
+        return first, (self.n - first if count is None else count)
+
+    def set_effect(self, slot, effect, first=0, count=None):
+        """One `desc.Effect` broadcast to the range, or a sequence of them (one per instance)."""
+        first, count = self._range(first, count)
+        if isinstance(effect, desc.Effect):
+            self._check(self._lib.oalsfx_batch_set_effect(self._h, first, count, slot, C.byref(effect), 0))
+        else:
+            arr = (desc.Effect * count)(*effect)
+            self._check(self._lib.oalsfx_batch_set_effect(self._h, first, count, slot, arr, C.sizeof(desc.Effect)))
+
+    def set_effect_type(self, slot, effect_type, first=0, count=None):
+        first, count = self._range(first, count)
+        self._check(self._lib.oalsfx_batch_set_effect_type(self._h, first, count, slot, effect_type))
+
+    def set_effect_props(self, slot, props_union, first=0, count=None):
+        first, count = self._range(first, count)
+        self._check(self._lib.oalsfx_batch_set_effect_props(self._h, first, count, slot, C.byref(props_union), 0))
+
+    def set_send_props(self, slot, gain, gain_hf, gain_lf, first=0, count=None):
+        first, count = self._range(first, count)
+        p = desc.SendProps(gain, gain_hf, gain_lf)
+        self._check(self._lib.oalsfx_batch_set_send_props(self._h, first, count, slot, C.byref(p)))
+
+    def get_effect(self, instance, slot, deferred=False):
+        e = desc.Effect()
+        self._check(self._lib.oalsfx_batch_get_effect(self._h, instance, slot, 1 if deferred else 0, C.byref(e)))
+        return e
+
+    def get_send_props(self, instance, slot, deferred=False):
+        p = desc.SendProps()
+        self._check(self._lib.oalsfx_batch_get_send_props(self._h, instance, slot, 1 if deferred else 0, C.byref(p)))
+        return p
+
+    def apply_changes(self, first=0, count=None):
+        first, count = self._range(first, count)
+        self._check(self._lib.oalsfx_batch_apply_changes(self._h, first, count))
+
+    # ---- the hot path ----
+    def mix(self, src):
+        """src: float32 array [n][frames][channels] on the host; returns the same shape."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        assert src.ndim == 3 and src.shape[0] == self.n and src.shape[2] == self.channels, src.shape
+        dst = np.empty_like(src)
+        self._check(self._lib.oalsfx_batch_mix(self._h, src.shape[1], src.ctypes.data_as(_fp), dst.ctypes.data_as(_fp)))
+        return dst
+
+    def mix_device(self, frames, src_ptr, dst_ptr, stream=None):
+        """Buffers already in device memory (raw addresses, e.g. torch.Tensor.data_ptr()); asynchronous."""
+        self._check(self._lib.oalsfx_batch_mix_device(self._h, frames, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        self._check(self._lib.oalsfx_batch_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.oalsfx_batch_stream(self._h)
+
+    def fill_synthetic(self, frames, buffer_index, dst_ptr, stream=None):
+        self._check(self._lib.oalsfx_batch_fill_synthetic(self._h, frames, buffer_index, C.c_void_p(dst_ptr), C.c_void_p(stream or 0)))
+
+    # ---- read-back ----
+    def read_slot(self, instance, slot):
+        p, s = desc.SlotParams(), desc.SlotState()
+        self._check(self._lib.oalsfx_batch_read_slot(self._h, instance, slot, C.byref(p), C.byref(s)))
+        return p, s
+
+    def read_ring(self, instance, slot):
+        n = self._lib.oalsfx_batch_read_ring(self._h, instance, slot, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        if n:
+            self._lib.oalsfx_batch_read_ring(self._h, instance, slot, out.ctypes.data_as(_fp), n)
+        return out
+
+    def read_source(self, instance):
+        p, s = desc.SourceParams(), desc.SourceState()
+        self._check(self._lib.oalsfx_batch_read_source(self._h, instance, C.byref(p), C.byref(s)))
+        return p, s
+
+    # ---- kernel timing (HIP events on the launch stream) ----
+    def kernel_timing(self, enable=True):
+        self._check(self._lib.oalsfx_batch_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_read(self, effect_type):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self._check(self._lib.oalsfx_batch_kernel_timing_read(self._h, effect_type, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class Api:
+    """One effect chain with the reference's method names; a `Batch` of one instance underneath."""
+
+    def __init__(self):
+        self._b = None
+        self._error = ""
+
+    def initialize(self, channel_format, sampling_rate, effect_count, device_id=0):
+        self.uninitialize()
+        try:
+            self._b = Batch(1, channel_format, sampling_rate, effect_count, device_id)
+        except BatchError as e:
+            self._error = str(e)
+            return False
+        return True
+
+    def is_initialized(self):
+        return self._b is not None
+
+    def uninitialize(self):
+        if self._b is not None:
+            self._b.close()
+            self._b = None
+
+    def get_error_message(self):
+        return self._error
+
+    def _guard(self, fn, fail=False):
+        if self._b is None:
+            self._error = "Not initialized."
+            return fail
+        try:
+            return fn()
+        except BatchError as e:
+            self._error = str(e)
+            return fail
+
+    def get_sampling_rate(self):
+        return self._guard(lambda: self._b.rate, 0)
+
+    def get_channel_format(self):
+        return self._guard(lambda: self._b.channel_format, desc.FMT_NONE)
+
+    def get_channel_count(self):
+        return self._guard(lambda: self._b.channels, 0)
+
+    def get_effect_count(self):
+        return self._guard(lambda: self._b.effect_count, 0)
+
+    def set_effect_type(self, index, effect_type):
+        return self._guard(lambda: self._b.set_effect_type(index, effect_type) or True)
+
+    def set_effect(self, index, effect):
+        # the reference's Api::set_effect stores the effect and returns false (src/oalsfxpp.cpp:3655-3657)
+        self._guard(lambda: self._b.set_effect(index, effect))
+        return False
+
+    def get_effect(self, index, deferred=False):
+        return self._guard(lambda: self._b.get_effect(0, index, deferred), None)
+
+    def set_send_props(self, index, gain, gain_hf, gain_lf):
+        return self._guard(lambda: self._b.set_send_props(index, gain, gain_hf, gain_lf) or True)
+
+    def apply_changes(self):
+        return self._guard(lambda: self._b.apply_changes() or True)
+
+    def mix(self, src):
+        """src: [frames][channels] float32; returns the mixed frames or None on failure."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        if src.size == 0:
+            return src.copy()
+        return self._guard(lambda: self._b.mix(src[None])[0], None)

@@ -1,0 +1,77 @@
+"""In-tree build of liboalsfx_hip.so (host update path + batch runtime + gfx950 kernels).
+
+    python -m oalsfxpp_amd.build        # or: __graft_entry__.build()
+
+hipcc cross-compiles for gfx950 without a GPU present.  Flags that matter for parity:
+-ffp-contract=off on host and device (the reference's arithmetic is unfused), no fast-math.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "liboalsfx_hip.so")
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+
+HOST_SOURCES = ["host/props.cpp", "host/panning.cpp", "host/update.cpp", "host/hostabi.cpp", "host/api.cpp"]
+HIP_SOURCES = ["hip/batch.cpp", "hip/reverb.hip", "hip/simple_effects.hip"]
+
+COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",
+          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "hip")]
+DEVICE = ["--offload-arch=gfx950", "-x", "hip", "-fgpu-flush-denormals-to-zero=0"] if False else ["--offload-arch=gfx950", "-x", "hip"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src,) + tuple(extra))
+
+
+def build_all(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = []
+    for d in (os.path.join(ROOT, "include"), os.path.join(CSRC, "host"), os.path.join(CSRC, "hip")):
+        headers += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp", ".inc"))]
+    objs = []
+    procs = []
+    for rel in HOST_SOURCES + HIP_SOURCES:
+        src = os.path.join(CSRC, rel)
+        obj = os.path.join(OBJ_DIR, rel.replace("/", "_") + ".o")
+        objs.append(obj)
+        if not (force or _newer(src, obj, headers)):
+            continue
+        cmd = [hipcc] + COMMON + (DEVICE if rel in HIP_SOURCES else []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((rel, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for rel, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"---- {rel} ----\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or not os.path.exists(OUT):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,615 @@
+// Batch runtime behind the C ABI of include/oalsfx_hip.h.
+//
+// Owns, for N independent instances: the API-visible property bookkeeping (host), the derived
+// descriptors (host shadow + device copy), the process-path state and delay rings (device only) and
+// the launch plan (per slot, per effect type, a device list of instance indices).  One call to
+// oalsfx_batch_mix* advances every instance by one buffer: the slot loop of the reference's
+// Api::Impl::mix_data (reference src/oalsfxpp.cpp:2984-3037) becomes, per slot, one kernel launch per
+// effect type present in that slot.
+//
+// There is no CPU implementation of the sample path in this library: without a usable HIP device
+// oalsfx_batch_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../host/core.hpp"
+#include "common.hpp"
+#include "oalsfx_hip.h"
+
+using namespace oalsfx_host;
+using oalsfx_hip::KernelCtx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+const char* const kErrNotSupportedFilters =
+    "Send filters (gain_hf / gain_lf != 1) are not implemented on the GPU path yet.";
+
+struct RingPool {
+    size_t slab_floats = 0;
+    std::vector<float*> free_clean; // zero-filled, never used since allocation
+    std::vector<float*> free_dirty;
+};
+
+struct TimedLaunch { hipEvent_t start, stop; int type; };
+
+} // namespace
+
+struct oalsfx_batch {
+    int n = 0, slots = 0, channels = 0, rate = 0, device = 0;
+    int format = 0;
+    DeviceDesc dev;
+    std::vector<InstanceHost> inst;
+
+    // host shadows
+    std::vector<oalsfx_slot_params> h_params;     // [n*slots]
+    std::vector<oalsfx_slot_state> h_state_init;  // [n*slots] staging for restarted slots
+    std::vector<oalsfx_source_params> h_source;   // [n]
+    std::vector<uint32_t> seq;                    // [n*slots]
+    std::vector<float*> h_rings;                  // [n*slots]
+    std::vector<size_t> ring_floats;              // [n*slots] size class of the slab held
+    std::vector<uint8_t> inst_dirty;              // [n]
+    std::vector<int> dirty_list;
+    bool lists_dirty = true;
+    bool filters_active = false;
+
+    // device
+    oalsfx_slot_params* d_params = nullptr;
+    oalsfx_slot_state* d_state = nullptr;
+    oalsfx_source_params* d_source = nullptr;
+    float** d_rings = nullptr;
+    float* d_tail = nullptr;
+    float* d_mixbuf = nullptr;
+    int* d_lists = nullptr;                       // [slots][n]
+    int list_offset[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
+    int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
+    std::map<size_t, RingPool> pools;
+    std::vector<void*> chunks;
+
+    // staging for host-pointer mixes
+    float* d_io_src = nullptr;
+    float* d_io_dst = nullptr;
+    size_t io_capacity = 0;
+
+    hipStream_t stream = nullptr;
+    const char* error = "";
+    std::string error_store;
+
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+
+    bool fail(const char* msg) { error = msg; return false; }
+    bool hip_ok(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return true;
+        error_store = std::string(what) + ": " + hipGetErrorString(e);
+        error = error_store.c_str();
+        return false;
+    }
+};
+
+namespace {
+
+constexpr const char* kErrRange = "Instance range is out of bounds.";
+constexpr const char* kErrSlot = "Effect index is out of range.";   // reference ApiErrorMessages::effect_index_out_of_range
+constexpr const char* kErrNoSrc = "No source samples.";              // reference ApiErrorMessages::no_src_samples
+constexpr const char* kErrNoDst = "No destination samples.";         // reference ApiErrorMessages::no_dst_samples
+
+bool range_ok(oalsfx_batch* b, int first, int count)
+{
+    if (first < 0 || count < 0 || first + count > b->n) return b->fail(kErrRange);
+    return true;
+}
+
+void mark_dirty(oalsfx_batch* b, int i)
+{
+    if (!b->inst_dirty[i]) {
+        b->inst_dirty[i] = 1;
+        b->dirty_list.push_back(i);
+    }
+}
+
+// copies [lo, hi) elements of a host shadow array to the device
+template <typename T>
+bool upload_range(oalsfx_batch* b, T* dev, const T* host, size_t lo, size_t hi)
+{
+    if (hi <= lo) return true;
+    return b->hip_ok(hipMemcpyAsync(dev + lo, host + lo, (hi - lo) * sizeof(T), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(H2D)");
+}
+
+// uploads the elements flagged in `flags` as maximal contiguous runs
+template <typename T>
+bool upload_flagged(oalsfx_batch* b, T* dev, const T* host, const std::vector<uint8_t>& flags)
+{
+    size_t i = 0;
+    const size_t n = flags.size();
+    while (i < n) {
+        if (!flags[i]) { ++i; continue; }
+        size_t j = i;
+        while (j < n && flags[j]) ++j;
+        if (!upload_range(b, dev, host, i, j)) return false;
+        i = j;
+    }
+    return true;
+}
+
+void release_slab(oalsfx_batch* b, size_t idx)
+{
+    if (b->h_rings[idx]) {
+        b->pools[b->ring_floats[idx]].free_dirty.push_back(b->h_rings[idx]);
+        b->h_rings[idx] = nullptr;
+        b->ring_floats[idx] = 0;
+    }
+}
+
+// Folds all pending property changes into descriptors, device state and the launch plan: what the
+// reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
+// plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
+bool sync_params(oalsfx_batch* b)
+{
+    if (b->dirty_list.empty()) return true;
+    const size_t total = static_cast<size_t>(b->n) * b->slots;
+    std::vector<uint8_t> up_params(total, 0), up_state(total, 0), up_source(b->n, 0);
+    std::map<size_t, int> need; // size class -> slabs needed
+    std::vector<size_t> restarted;
+    bool any_type_change = false;
+
+    for (int i : b->dirty_list) {
+        InstanceHost& h = b->inst[i];
+        bool updated = false;
+        for (int s = 0; s < b->slots; ++s) {
+            if (!h.slot_changed[s]) continue;
+            h.slot_changed[s] = false;
+            updated = true;
+            const size_t idx = static_cast<size_t>(i) * b->slots + s;
+            oalsfx_slot_params& p = b->h_params[idx];
+            derive_slot(b->dev, h.active[s], p);
+            p.update_seq = ++b->seq[idx];
+            up_params[idx] = 1;
+            if (h.slot_retyped[s]) {
+                h.slot_retyped[s] = false;
+                any_type_change = true;
+                reset_slot_state(p.type, b->h_state_init[idx]);
+                b->h_state_init[idx].seen_seq = p.update_seq - 1;
+                up_state[idx] = 1;
+                restarted.push_back(idx);
+                release_slab(b, idx);
+                const size_t floats = static_cast<size_t>(ring_floats_for(p.type, b->rate));
+                if (floats) need[floats] += 1;
+            }
+        }
+        if (h.source_changed) {
+            h.source_changed = false;
+            updated = true;
+        }
+        if (updated) {
+            int types[OALSFX_MAX_SLOTS] = {};
+            for (int s = 0; s < b->slots; ++s) types[s] = static_cast<int>(h.active[s].type_);
+            derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, b->h_source[i]);
+            up_source[i] = 1;
+        }
+        b->inst_dirty[i] = 0;
+    }
+    b->dirty_list.clear();
+
+    // send filters: only the pass-through path exists on the GPU so far
+    b->filters_active = false;
+    for (int i = 0; i < b->n && !b->filters_active; ++i) {
+        if (b->h_source[i].direct.filter_type != OALSFX_AF_NONE) b->filters_active = true;
+        for (int s = 0; s < b->slots; ++s)
+            if (b->h_source[i].aux[s].filter_type != OALSFX_AF_NONE) b->filters_active = true;
+    }
+
+    // ring slabs: grow each size class once, zero fresh chunks in one memset
+    for (auto& kv : need) {
+        RingPool& pool = b->pools[kv.first];
+        pool.slab_floats = kv.first;
+        const int have = static_cast<int>(pool.free_clean.size() + pool.free_dirty.size());
+        const int grow = kv.second - have;
+        if (grow > 0) {
+            void* chunk = nullptr;
+            const size_t bytes = static_cast<size_t>(grow) * kv.first * sizeof(float);
+            if (!b->hip_ok(hipMalloc(&chunk, bytes), "hipMalloc(rings)")) return false;
+            if (!b->hip_ok(hipMemsetAsync(chunk, 0, bytes, b->stream), "hipMemsetAsync(rings)")) return false;
+            b->chunks.push_back(chunk);
+            // hand the slabs out in address order so that consecutive instances get consecutive slabs
+            for (int k = grow - 1; k >= 0; --k) pool.free_clean.push_back(static_cast<float*>(chunk) + static_cast<size_t>(k) * kv.first);
+        }
+    }
+    bool rings_changed = false;
+    for (size_t idx : restarted) {
+        const size_t floats = static_cast<size_t>(ring_floats_for(b->h_params[idx].type, b->rate));
+        if (!floats) continue;
+        RingPool& pool = b->pools[floats];
+        float* slab = nullptr;
+        if (!pool.free_clean.empty()) {
+            slab = pool.free_clean.back();
+            pool.free_clean.pop_back();
+        } else {
+            slab = pool.free_dirty.back();
+            pool.free_dirty.pop_back();
+            if (!b->hip_ok(hipMemsetAsync(slab, 0, floats * sizeof(float), b->stream), "hipMemsetAsync(ring)")) return false;
+        }
+        b->h_rings[idx] = slab;
+        b->ring_floats[idx] = floats;
+        rings_changed = true;
+    }
+    if (rings_changed || !restarted.empty()) {
+        if (!upload_range(b, b->d_rings, b->h_rings.data(), 0, total)) return false;
+    }
+    if (!upload_flagged(b, b->d_params, b->h_params.data(), up_params)) return false;
+    if (!upload_flagged(b, b->d_state, b->h_state_init.data(), up_state)) return false;
+    if (!upload_flagged(b, b->d_source, b->h_source.data(), up_source)) return false;
+
+    if (any_type_change || b->lists_dirty) {
+        std::vector<int> lists(total);
+        for (int s = 0; s < b->slots; ++s) {
+            int off = 0;
+            for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) {
+                b->list_offset[s][t] = s * b->n + off;
+                int cnt = 0;
+                for (int i = 0; i < b->n; ++i)
+                    if (b->h_params[static_cast<size_t>(i) * b->slots + s].type == t) lists[s * b->n + off + cnt++] = i;
+                b->list_count[s][t] = cnt;
+                off += cnt;
+            }
+        }
+        if (!upload_range(b, b->d_lists, lists.data(), 0, total)) return false;
+        // the upload above reads a local vector: it must finish before the vector dies
+        if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return false;
+        b->lists_dirty = false;
+    }
+    // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
+    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
+}
+
+bool ensure_mixbuf(oalsfx_batch* b)
+{
+    if (b->d_mixbuf || b->slots == 1) return true;
+    const size_t bytes = static_cast<size_t>(b->n) * b->channels * OALSFX_MAX_CHUNK * sizeof(float);
+    return b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
+}
+
+void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+{
+    const int count = b->list_count[slot][type];
+    if (count == 0) return;
+    if (type == OALSFX_NULL && flags == 0) return; // a null effect in the middle of the chain does nothing
+    const int* list = b->d_lists + b->list_offset[slot][type];
+    TimedLaunch tl{};
+    if (b->timing) {
+        hipEventCreate(&tl.start);
+        hipEventCreate(&tl.stop);
+        tl.type = type;
+        hipEventRecord(tl.start, stream);
+    }
+    if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) oalsfx_hip::launch_reverb(ctx, slot, list, count, flags, stream);
+    else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
+    if (b->timing) {
+        hipEventRecord(tl.stop, stream);
+        b->timed.push_back(tl);
+    }
+}
+
+bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
+{
+    if (!sync_params(b)) return false;
+    if (b->filters_active) return b->fail(kErrNotSupportedFilters);
+    if (!ensure_mixbuf(b)) return false;
+    KernelCtx ctx{};
+    ctx.params = b->d_params;
+    ctx.state = b->d_state;
+    ctx.rings = b->d_rings;
+    ctx.source = b->d_source;
+    ctx.src_tail = b->d_tail;
+    ctx.mixbuf = b->d_mixbuf;
+    ctx.slots = b->slots;
+    ctx.channels = b->channels;
+    ctx.io_stride = static_cast<long long>(frames) * b->channels;
+    // Api::mix chunking (reference src/oalsfxpp.cpp:3818-3826)
+    for (int done = 0; done < frames;) {
+        const int n = std::min(frames - done, OALSFX_MAX_CHUNK);
+        ctx.src = src + static_cast<size_t>(done) * b->channels;
+        ctx.dst = dst + static_cast<size_t>(done) * b->channels;
+        ctx.frames = n;
+        for (int s = 0; s < b->slots; ++s) {
+            const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0);
+            for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) launch_type(b, t, ctx, s, flags, stream);
+        }
+        done += n;
+    }
+    return b->hip_ok(hipGetLastError(), "kernel launch");
+}
+
+} // namespace
+
+extern "C" {
+
+const char* oalsfx_last_error(void) { return g_last_error.c_str(); }
+
+oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampling_rate, int effect_count, int device_id)
+{
+    g_last_error.clear();
+    const int channels = channel_count_of(static_cast<oalsfxpp::ChannelFormat>(channel_format));
+    // same checks and messages as Api::Impl::initialize (reference src/oalsfxpp.cpp:2853-2871)
+    if (channels == 0) { g_last_error = "Invalid channel format."; return nullptr; }
+    if (sampling_rate < min_sampling_rate) { g_last_error = "Sampling rate is out of range."; return nullptr; }
+    if (effect_count <= 0 || effect_count > OALSFX_MAX_SLOTS) { g_last_error = "Effect count is out of range."; return nullptr; }
+    if (n_instances <= 0) { g_last_error = "Instance count is out of range."; return nullptr; }
+
+    int device_count = 0;
+    if (hipGetDeviceCount(&device_count) != hipSuccess || device_count <= 0) {
+        g_last_error = "No HIP device available: the effect process path has no CPU fallback.";
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= device_count) { g_last_error = "HIP device ordinal is out of range."; return nullptr; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_last_error = "hipSetDevice failed."; return nullptr; }
+
+    auto* b = new (std::nothrow) oalsfx_batch{};
+    if (!b) { g_last_error = "Failed to allocate the batch."; return nullptr; }
+    b->n = n_instances;
+    b->slots = effect_count;
+    b->channels = channels;
+    b->rate = sampling_rate;
+    b->format = channel_format;
+    b->device = device_id;
+    b->dev.init(static_cast<oalsfxpp::ChannelFormat>(channel_format), sampling_rate);
+    b->channels = b->dev.channels;
+    const size_t total = static_cast<size_t>(n_instances) * effect_count;
+    b->inst.resize(n_instances);
+    b->h_params.assign(total, oalsfx_slot_params{});
+    b->h_state_init.assign(total, oalsfx_slot_state{});
+    b->h_source.assign(n_instances, oalsfx_source_params{});
+    b->seq.assign(total, 0);
+    b->h_rings.assign(total, nullptr);
+    b->ring_floats.assign(total, 0);
+    b->inst_dirty.assign(n_instances, 0);
+    for (int i = 0; i < n_instances; ++i) {
+        b->inst[i].initialize(effect_count);
+        mark_dirty(b, i);
+    }
+
+    bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_params), total * sizeof(oalsfx_slot_params)), "hipMalloc(params)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_slot_state)), "hipMalloc(state)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_tail), static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float)), "hipMalloc(tail)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_tail, 0, static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float), b->stream), "hipMemsetAsync(tail)");
+    if (!ok) {
+        g_last_error = b->error;
+        oalsfx_batch_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+
+void oalsfx_batch_destroy(oalsfx_batch* b)
+{
+    if (!b) return;
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    for (void* c : b->chunks) hipFree(c);
+    hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_tail);
+    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+const char* oalsfx_batch_error(const oalsfx_batch* b) { return b ? b->error : g_last_error.c_str(); }
+int oalsfx_batch_instances(const oalsfx_batch* b) { return b->n; }
+int oalsfx_batch_channels(const oalsfx_batch* b) { return b->channels; }
+int oalsfx_batch_sampling_rate(const oalsfx_batch* b) { return b->rate; }
+int oalsfx_batch_effect_count(const oalsfx_batch* b) { return b->slots; }
+
+int oalsfx_batch_set_effect(oalsfx_batch* b, int first, int count, int slot, const oalsfx_effect* effects, int stride_bytes)
+{
+    if (!range_ok(b, first, count)) return 0;
+    if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    const auto* base = reinterpret_cast<const unsigned char*>(effects);
+    for (int i = 0; i < count; ++i)
+        std::memcpy(&b->inst[first + i].deferred[slot], base + static_cast<size_t>(i) * stride_bytes, sizeof(oalsfx_effect));
+    return 1;
+}
+
+int oalsfx_batch_set_effect_type(oalsfx_batch* b, int first, int count, int slot, int effect_type)
+{
+    if (!range_ok(b, first, count)) return 0;
+    if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    for (int i = 0; i < count; ++i) b->inst[first + i].deferred[slot].set_type_and_defaults(static_cast<oalsfxpp::EffectType>(effect_type));
+    return 1;
+}
+
+int oalsfx_batch_set_effect_props(oalsfx_batch* b, int first, int count, int slot, const void* props, int stride_bytes)
+{
+    if (!range_ok(b, first, count)) return 0;
+    if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    const auto* base = static_cast<const unsigned char*>(props);
+    for (int i = 0; i < count; ++i)
+        std::memcpy(&b->inst[first + i].deferred[slot].props_, base + static_cast<size_t>(i) * stride_bytes, sizeof(oalsfxpp::EffectProps));
+    return 1;
+}
+
+int oalsfx_batch_set_send_props(oalsfx_batch* b, int first, int count, int slot, const oalsfx_send_props* props)
+{
+    if (!range_ok(b, first, count)) return 0;
+    if (slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    oalsfxpp::SendProps p;
+    p.gain_ = props->gain; p.gain_hf_ = props->gain_hf; p.gain_lf_ = props->gain_lf;
+    for (int i = 0; i < count; ++i) {
+        InstanceHost& h = b->inst[first + i];
+        // direct: deferred copy; auxiliary: the reference writes the active properties (src/oalsfxpp.cpp:3728-3733)
+        if (slot < 0) h.direct_deferred = p;
+        else h.aux_props[slot] = p;
+    }
+    return 1;
+}
+
+int oalsfx_batch_get_effect(const oalsfx_batch* b, int instance, int slot, int deferred, oalsfx_effect* out)
+{
+    if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
+    const InstanceHost& h = b->inst[instance];
+    std::memcpy(out, deferred ? &h.deferred[slot] : &h.active[slot], sizeof(oalsfx_effect));
+    return 1;
+}
+
+int oalsfx_batch_get_send_props(const oalsfx_batch* b, int instance, int slot, int deferred, oalsfx_send_props* out)
+{
+    if (instance < 0 || instance >= b->n || slot >= b->slots) return 0;
+    const InstanceHost& h = b->inst[instance];
+    const oalsfxpp::SendProps& p = slot < 0 ? (deferred ? h.direct_deferred : h.direct_props) : (deferred ? h.aux_deferred[slot] : h.aux_props[slot]);
+    out->gain = p.gain_; out->gain_hf = p.gain_hf_; out->gain_lf = p.gain_lf_;
+    return 1;
+}
+
+int oalsfx_batch_apply_changes(oalsfx_batch* b, int first, int count)
+{
+    if (!range_ok(b, first, count)) return 0;
+    for (int i = first; i < first + count; ++i) {
+        InstanceHost& h = b->inst[i];
+        h.apply_changes();
+        bool dirty = h.source_changed;
+        for (int s = 0; s < b->slots; ++s) dirty |= h.slot_changed[s];
+        if (dirty) mark_dirty(b, i);
+    }
+    return 1;
+}
+
+int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream)
+{
+    if (frames == 0) return 1;
+    if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
+    if (!src_dev) return b->fail(kErrNoSrc) ? 1 : 0;
+    if (!dst_dev) return b->fail(kErrNoDst) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    return mix_device(b, frames, src_dev, dst_dev, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream) ? 1 : 0;
+}
+
+int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host)
+{
+    if (frames == 0) return 1;
+    if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
+    if (!src_host) return b->fail(kErrNoSrc) ? 1 : 0;
+    if (!dst_host) return b->fail(kErrNoDst) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    const size_t floats = static_cast<size_t>(b->n) * frames * b->channels;
+    if (floats > b->io_capacity) {
+        hipFree(b->d_io_src); hipFree(b->d_io_dst);
+        b->d_io_src = b->d_io_dst = nullptr;
+        b->io_capacity = 0;
+        if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_io_src), floats * sizeof(float)), "hipMalloc(io)")) return 0;
+        if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_io_dst), floats * sizeof(float)), "hipMalloc(io)")) return 0;
+        b->io_capacity = floats;
+    }
+    if (!b->hip_ok(hipMemcpyAsync(b->d_io_src, src_host, floats * sizeof(float), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(src)")) return 0;
+    if (!mix_device(b, frames, b->d_io_src, b->d_io_dst, b->stream)) return 0;
+    if (!b->hip_ok(hipMemcpyAsync(dst_host, b->d_io_dst, floats * sizeof(float), hipMemcpyDeviceToHost, b->stream), "hipMemcpyAsync(dst)")) return 0;
+    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 1 : 0;
+}
+
+int oalsfx_batch_synchronize(oalsfx_batch* b)
+{
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 1 : 0;
+}
+
+void* oalsfx_batch_stream(oalsfx_batch* b) { return b->stream; }
+
+int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_params* params, oalsfx_slot_state* state)
+{
+    if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return b->fail(kErrRange) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!sync_params(b)) return 0;
+    const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
+    if (params) *params = b->h_params[idx];
+    if (state) {
+        if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+        if (!b->hip_ok(hipMemcpy(state, b->d_state + idx, sizeof(*state), hipMemcpyDeviceToHost), "hipMemcpy(state)")) return 0;
+    }
+    return 1;
+}
+
+int oalsfx_batch_read_ring(oalsfx_batch* b, int instance, int slot, float* out, int max_floats)
+{
+    if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b)) return 0;
+    const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
+    const int floats = static_cast<int>(b->ring_floats[idx]);
+    if (out && floats) {
+        hipStreamSynchronize(b->stream);
+        const int n = std::min(floats, max_floats);
+        if (!b->hip_ok(hipMemcpy(out, b->h_rings[idx], static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy(ring)")) return 0;
+    }
+    return floats;
+}
+
+int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params* params, oalsfx_source_state* state)
+{
+    if (instance < 0 || instance >= b->n) return b->fail(kErrRange) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!sync_params(b)) return 0;
+    if (params) *params = b->h_source[instance];
+    if (state) {
+        // pass-through sends keep the last two input samples on both sides of every filter
+        // (reference process_pass_through, src/oalsfxpp.cpp:1038-1056)
+        std::memset(state, 0, sizeof(*state));
+        float tail[OALSFX_MAX_CHANNELS][2];
+        hipStreamSynchronize(b->stream);
+        if (!b->hip_ok(hipMemcpy(tail, b->d_tail + static_cast<size_t>(instance) * b->channels * 2, sizeof(float) * 2 * b->channels, hipMemcpyDeviceToHost), "hipMemcpy(tail)")) return 0;
+        for (int send = 0; send <= b->slots; ++send) {
+            if (send > 0 && b->h_source[instance].aux[send - 1].out_channels == 0) continue; // null slot: send disabled
+            for (int c = 0; c < b->channels; ++c)
+                for (int k = 0; k < 2; ++k) {
+                    state->lp[send][c].x[k] = state->lp[send][c].y[k] = tail[c][k];
+                    state->hp[send][c].x[k] = state->hp[send][c].y[k] = tail[c][k];
+                }
+        }
+    }
+    return 1;
+}
+
+int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_index, float* dst_dev, void* hip_stream)
+{
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    oalsfx_hip::launch_fill_synthetic(dst_dev, b->n, frames * b->channels, buffer_index, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream);
+    return b->hip_ok(hipGetLastError(), "fill_synthetic") ? 1 : 0;
+}
+
+int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable)
+{
+    for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    b->timed.clear();
+    b->timing = enable != 0;
+    return 1;
+}
+
+int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms)
+{
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    int n = 0;
+    double ms = 0.0;
+    for (auto& t : b->timed) {
+        if (t.type != effect_type) continue;
+        if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return 0;
+        float e = 0.0F;
+        if (!b->hip_ok(hipEventElapsedTime(&e, t.start, t.stop), "hipEventElapsedTime")) return 0;
+        ms += e;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    return 1;
+}
+
+} // extern "C"

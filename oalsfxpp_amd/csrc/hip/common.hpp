@@ -1,0 +1,123 @@
+// Shared declarations of the HIP side: launch context, device helpers, launcher prototypes.
+//
+// Build flags that matter for parity (set in oalsfxpp_amd/build.py): -ffp-contract=off (no FMA
+// contraction: the reference is evaluated with separately rounded mul/add, SURVEY 7 hard part 1),
+// no fast-math, IEEE division/sqrt (hipcc default), fp32 denormals on (gfx9 default).
+#ifndef OALSFX_HIP_COMMON_HPP
+#define OALSFX_HIP_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "oalsfx_desc.h"
+
+namespace oalsfx_hip {
+
+// What every effect kernel needs to find its instance's data.  Passed by value.
+struct KernelCtx {
+    const oalsfx_slot_params* params;   // [instance][slots]
+    oalsfx_slot_state* state;           // [instance][slots]
+    float* const* rings;                // [instance][slots] -> ring slab of that slot (or nullptr)
+    const oalsfx_source_params* source; // [instance]
+    float* src_tail;                    // [instance][channels][2]: last two input frames (newest first)
+    const float* src;                   // [instance][frames][channels] interleaved input of this chunk
+    float* dst;                         // [instance][frames][channels] interleaved output of this chunk
+    float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
+    int slots;
+    int channels;
+    int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
+    long long io_stride;                // floats between consecutive instances in src / dst
+};
+
+// Flags of one launch: which duties of the mix loop this slot's kernel performs.
+enum : int {
+    kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
+    kLast = 2,  // last slot: write the interleaved output instead of mixbuf
+};
+
+constexpr int kWave = 64;
+
+// ---- launchers (defined next to their kernels) ----
+void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
+
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ bool audible(float g) { return fabsf(g) > OALSFX_SILENCE_GAIN; }
+
+__device__ __forceinline__ float lerpf(float a, float b, float mu) { return a + ((b - a) * mu); }
+
+// ---------------------------------------------------------------------------------------------
+// sinf with the results of the reference's libm (glibc 2.35 x86-64 FMA build).  The reference
+// truncates sin()-derived values to integer delay taps inside process loops (reference
+// src/oalsfxpp.cpp:4273, 7454-7465), so the device must reproduce that libm bit for bit rather than
+// use the device math library.  Algorithm: quadrant reduction and polynomial in double precision
+// (glibc sysdeps/ieee754/flt-32/s_sinf.c, ARM optimized-routines), every a*b+c fused.
+// Valid for |y| < 120, which covers every argument the process path forms.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float glibc_sinf_poly(double x, double x2, bool negate_cos, int n)
+{
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        const double x7 = x3 * x2;
+        const double s = fma(x3, -0x1.555545995a603p-3, x);
+        return (float)fma(x7, s1, s);
+    }
+    const double sg = negate_cos ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double c2 = fma(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+    const double c1 = fma(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0);
+    const double x6 = x4 * x2;
+    const double c = fma(x4, sg * 0x1.55553e1068f19p-5, c1);
+    return (float)fma(x6, c2, c);
+}
+
+__device__ __forceinline__ float glibc_sinf(float y)
+{
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ff;
+    double x = (double)y;
+    if (top < 0x3f4) {            // |y| < 0.75 region the libm treats without reduction (abstop12(pi/4))
+        if (top < 0x398) return y; // |y| < 2^-12
+        return glibc_sinf_poly(x, x * x, false, 0);
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = fma(-(double)n, 0x1.921FB54442D18p0, x);
+    const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return glibc_sinf_poly(x * s, x * x, (n & 2) != 0, n);
+}
+
+// lround() for floats: nearest, halfway cases away from zero.
+__device__ __forceinline__ int lround_away(float x)
+{
+    float t = truncf(x);
+    if (fabsf(x - t) >= 0.5f) t += copysignf(1.0f, x);
+    return (int)t;
+}
+
+// Direct-form-I biquad step with the reference's association (reference FilterState::process,
+// src/oalsfxpp.cpp:1009-1014).
+__device__ __forceinline__ float biquad_step(const oalsfx_biquad_t& c, oalsfx_hist_t& h, float x)
+{
+    const float y = (c.b0 * x) + (c.b1 * h.x[0]) + (c.b2 * h.x[1]) - (c.a1 * h.y[0]) - (c.a2 * h.y[1]);
+    h.x[1] = h.x[0];
+    h.x[0] = x;
+    h.y[1] = h.y[0];
+    h.y[0] = y;
+    return y;
+}
+
+// Synthetic benchmark input, identical to oracle_synth.
+__device__ __forceinline__ uint32_t synth_seed(uint32_t instance, uint32_t buffer_index)
+{
+    uint32_t x = 0x9E3779B9u ^ (instance * 2654435761u) ^ buffer_index;
+    return x == 0 ? 1u : x;
+}
+
+#endif // __HIPCC__
+
+} // namespace oalsfx_hip
+
+#endif

@@ -1,0 +1,593 @@
+// Reverb / EAX reverb process kernel for gfx950 (the headline kernel).
+//
+// Replaces ReverbEffectState::do_process and everything under it (reference
+// src/oalsfxpp.cpp:6078-6170, 7358-7903) plus, when this slot is first / last, the dry mix of
+// mix_source (src/oalsfxpp.cpp:2917-2950) and the interleave of write_f32 (src/oalsfxpp.cpp:3414-3431).
+//
+// Mapping (MI355X-first):
+//   * one 64-lane wavefront per effect instance; 4 independent wavefronts per 256-thread workgroup,
+//     no workgroup barrier anywhere, so every branch below is wave-uniform (parameters, fade state and
+//     tile sizes are per instance);
+//   * lanes are consecutive sample times of a tile of <= 64 frames; each lane carries the 4-line
+//     A-format vector of its sample in registers, so the scattering matrices are register math;
+//   * every delay ring is stored per line (line j of ring r is one contiguous power-of-two ring), so
+//     a tap read or a ring write of a tile is one contiguous 256-byte wave access;
+//   * feedback paths (the two vector all-passes, the modulated late line) are honoured by cutting a
+//     tile into sub-blocks no longer than the shortest positive feedback delay (23+ samples at
+//     48 kHz, so usually the whole tile); a delay of 0 in a feedback ring reads the slot before it is
+//     written (the reference's read-before-write order) and needs no cut;
+//   * the second-order input shelves and the first-order T60 sections are serial recurrences that
+//     must round exactly like the reference: their feed-forward half is evaluated per lane, the
+//     feedback half runs on 4 "chain" lanes (one per line) over the tile via an LDS transpose.
+//
+// Bit-exactness: compiled with -ffp-contract=off; expression association follows the reference.
+#include <float.h>
+
+#include "common.hpp"
+
+namespace oalsfx_hip {
+
+namespace {
+
+constexpr int kRow = 68;          // 4 (history prefix, 16-byte aligned data) + 64 samples
+constexpr int kRows = 4 * 4;      // 4 row groups x 4 lines
+constexpr int kRngFloats = OALSFX_RV_MAX_UPDATE;
+
+template <int CH>
+struct Lds {
+    static constexpr int kChains = 8 * CH; // (early|late) x 4 lines x channels gain ramps
+    static constexpr int kFloats = kRows * kRow + kRngFloats + kChains * 64;
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    // LDS hand-off between lanes of one wavefront: order the compiler, the hardware keeps a wave's
+    // LDS operations in order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void mem_sync()
+{
+    // ring stores of this wavefront must be complete before later tap loads of other lanes
+    // (same CU, same L1: workgroup scope is sufficient and costs one s_waitcnt vmcnt(0))
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ int min_positive(int limit, int d) { return (d > 0 && d < limit) ? d : limit; }
+
+struct Ring {
+    float* base; // line 0
+    int len;
+    int mask;
+    __device__ __forceinline__ float* line(int j) const { return base + j * len; }
+};
+
+// delay_out_faded / delay_out_unfaded (reference src/oalsfxpp.cpp:7358-7399)
+__device__ __forceinline__ float tap(const Ring& r, int j, bool faded, int pos0, int pos1, float mu)
+{
+    const float* l = r.line(j);
+    const float a = l[pos0 & r.mask];
+    if (!faded) return a;
+    const float b = l[pos1 & r.mask];
+    return lerpf(a, b, mu);
+}
+
+// vector_partial_scatter (reference src/oalsfxpp.cpp:7510-7521)
+__device__ __forceinline__ void scatter(float v[4], float x, float y)
+{
+    const float f0 = v[0], f1 = v[1], f2 = v[2], f3 = v[3];
+    v[0] = (x * f0) + (y * (f1 + -f2 + f3));
+    v[1] = (x * f1) + (y * (-f0 + f2 + f3));
+    v[2] = (x * f2) + (y * (f0 + -f1 + f3));
+    v[3] = (x * f3) + (y * (-f0 + -f1 + -f2));
+}
+
+// Serial half of a biquad over `n` samples of one LDS row: y = (u - a1*y1) - a2*y2.
+// in: row_u[4+i] = feed-forward sums; out: row_y[4+i]; row_y[3], row_y[2] hold y[-1], y[-2].
+__device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, int n, float a1, float a2)
+{
+    float y1 = row_y[3], y2 = row_y[2];
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(row_u + 4 + i);
+        float4 y;
+        y.x = (u.x - (a1 * y1)) - (a2 * y2);
+        y.y = (u.y - (a1 * y.x)) - (a2 * y1);
+        y.z = (u.z - (a1 * y.y)) - (a2 * y.x);
+        y.w = (u.w - (a1 * y.z)) - (a2 * y.y);
+        *reinterpret_cast<float4*>(row_y + 4 + i) = y;
+        y2 = y.z;
+        y1 = y.w;
+    }
+    for (; i < n; ++i) {
+        const float y = (row_u[4 + i] - (a1 * y1)) - (a2 * y2);
+        row_y[4 + i] = y;
+        y2 = y1;
+        y1 = y;
+    }
+}
+
+// After a tile of n samples the last two entries become the history prefix of the next tile.
+__device__ __forceinline__ void roll_history(float* row, int n)
+{
+    const float a = row[4 + n - 2]; // n == 1 reads row[3], the previous newest sample
+    const float b = row[4 + n - 1];
+    row[2] = a;
+    row[3] = b;
+}
+
+} // namespace
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+{
+    constexpr int NQ = Lds<CH>::kChains;
+    __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];
+
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + wave_in_block;
+    if (w >= count) return;
+    const int lane = threadIdx.x & 63;
+
+    float* lds = lds_all[wave_in_block];
+    // row groups: 0 = A-format input (lp x), 1 = lp output (lp y, hp x), 2 = hp output (hp y), 3 = scan scratch (u / T60)
+    auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
+    float* rng = lds + kRows * kRow;
+    float* gseq = rng + kRngFloats;
+
+    const int inst = __builtin_amdgcn_readfirstlane(list[w]);
+    const int channels = (CH == 8) ? ctx.channels : CH;
+    const int frames = ctx.frames;
+    const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
+    const oalsfx_slot_params& SP = ctx.params[sidx];
+    const oalsfx_reverb_params& P = SP.u.reverb;
+    oalsfx_slot_state& SS = ctx.state[sidx];
+    oalsfx_reverb_state& S = SS.u.reverb;
+    const oalsfx_source_params& SRC = ctx.source[inst];
+    float* slab = ctx.rings[sidx];
+    const bool first = (flags & kFirst) != 0;
+    const bool last = (flags & kLast) != 0;
+    const bool eax = P.is_eax != 0;
+
+    Ring ring[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        ring[r].base = slab + P.ring_off[r];
+        ring[r].len = P.ring_len[r];
+        ring[r].mask = P.ring_len[r] - 1;
+    }
+
+    // ---- instance state into registers (all wave-uniform) ----
+    int fade_count = S.fade_count, offset = S.offset, mod_index = S.mod_index, mod_range = S.mod_range;
+    float mod_filter = S.mod_filter;
+    int cur_etap[4], cur_eap[4], cur_eline[4], cur_ltap[4], cur_lap[4], cur_lline[4];
+    int new_etap[4], new_eap[4], new_eline[4], new_ltap[4], new_lap[4], new_lline[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cur_etap[j] = S.cur_early_tap[j]; cur_eap[j] = S.cur_early_ap_off[j]; cur_eline[j] = S.cur_early_line_off[j];
+        cur_ltap[j] = S.cur_late_tap[j]; cur_lap[j] = S.cur_late_ap_off[j]; cur_lline[j] = S.cur_late_line_off[j];
+        new_etap[j] = P.early_tap[j]; new_eap[j] = P.early_ap_off[j]; new_eline[j] = P.early_line_off[j];
+        new_ltap[j] = P.late_tap[j]; new_lap[j] = P.late_ap_off[j]; new_lline[j] = P.late_line_off[j];
+    }
+
+    // pending parameter update: what do_update does to state (reference src/oalsfxpp.cpp:7028-7031, 6062-6075)
+    if (SS.seen_seq != SP.update_seq) {
+        mod_index = static_cast<int>(static_cast<long long>(mod_index) * P.mod_range / mod_range);
+        mod_range = P.mod_range;
+        bool differ = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            differ |= (new_etap[j] != cur_etap[j]) | (new_eap[j] != cur_eap[j]) | (new_eline[j] != cur_eline[j]) |
+                      (new_ltap[j] != cur_ltap[j]) | (new_lap[j] != cur_lap[j]) | (new_lline[j] != cur_lline[j]);
+        if (differ) fade_count = 0;
+    }
+
+    // ---- chain lanes: filter histories into the LDS row prefixes ----
+    if (lane < 4) {
+        float* r0 = row(0, lane); float* r1 = row(1, lane); float* r2 = row(2, lane);
+        r0[3] = S.lp[lane].x[0]; r0[2] = S.lp[lane].x[1];
+        r1[3] = S.lp[lane].y[0]; r1[2] = S.lp[lane].y[1];
+        r2[3] = S.hp[lane].y[0]; r2[2] = S.hp[lane].y[1];
+    }
+    float t60_s00 = 0.f, t60_s01 = 0.f, t60_s10 = 0.f, t60_s11 = 0.f;
+    if (lane < 4) {
+        t60_s00 = S.t60[lane][0][0]; t60_s01 = S.t60[lane][0][1];
+        t60_s10 = S.t60[lane][1][0]; t60_s11 = S.t60[lane][1][1];
+    }
+
+    // ---- chain lanes: output gain ramps. chain q = (stage*4 + line)*CH + channel ----
+    const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
+    const bool q_valid = (lane < NQ) && (q_chan < channels);
+    float g_cur = 0.f, g_tgt = 0.f;
+    if (q_valid) {
+        g_cur = q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan];
+        g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
+    }
+
+    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
+    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
+    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
+
+    const float b2a = 0.288675134595F; // |b2a| entries (reference src/oalsfxpp.cpp:6377-6383), signs applied below
+    const float apc = P.ap_feed_coeff, mx = P.mix_x, my = P.mix_y;
+
+    for (int base = 0; base < frames;) {
+        int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
+        if (OALSFX_RV_FADE_SAMPLES - fade_count > 0) todo = min(todo, OALSFX_RV_FADE_SAMPLES - fade_count);
+        const bool faded = fade_count < OALSFX_RV_FADE_SAMPLES; // fade < 1.0
+        const int counter = frames - base;
+
+        // output gain ramps of this chunk (MixHelpers::mix, reference src/oalsfxpp.cpp:2762-2786)
+        const float delta = 1.0F / static_cast<float>(counter);
+        const float g_step = (g_tgt - g_cur) * delta;
+        const bool g_ramp = q_valid && (fabsf(g_step) > FLT_EPSILON);
+        const unsigned long long ramp_mask = __ballot(g_ramp);
+        float g_run = g_cur;
+
+        // modulation depth smoother: a serial lerp chain over the chunk (reference src/oalsfxpp.cpp:7462)
+        const bool mod_active = (P.mod_depth != 0.0F) || (mod_filter != 0.0F);
+        if (mod_active) {
+            if (lane == 0) {
+                float r = mod_filter;
+                for (int i = 0; i < todo; ++i) {
+                    r = lerpf(r, P.mod_depth, P.mod_coeff);
+                    rng[i] = r;
+                }
+            }
+            wave_sync();
+        }
+
+        // early / late feedback limits: the shortest positive all-pass delay in use
+        int eap_limit = 64, lap_limit = 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            eap_limit = min_positive(eap_limit, cur_eap[j]);
+            lap_limit = min_positive(lap_limit, cur_lap[j]);
+            if (faded) {
+                eap_limit = min_positive(eap_limit, new_eap[j]);
+                lap_limit = min_positive(lap_limit, new_lap[j]);
+            }
+        }
+
+        for (int done = 0; done < todo; done += 64) {
+            const int L = min(64, todo - done);
+            const bool act = lane < L;
+            const int t = offset + done + lane;                 // absolute sample index of this lane
+            const int pos = base + done + lane;                 // index inside the caller's chunk
+            const float fade = static_cast<float>(fade_count + done + lane) * (1.0F / OALSFX_RV_FADE_SAMPLES);
+
+            // ---------------- input: source frame -> dry mix, B-format send, A-format ----------------
+            float in[CH];
+            float out[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { in[c] = 0.0F; out[c] = 0.0F; }
+            if (act) {
+                if (CH == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(pos) * 2);
+                    in[0] = v.x; in[CH - 1] = v.y;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if (c < channels) in[c] = src[static_cast<size_t>(pos) * channels + c];
+                }
+            }
+            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (c >= channels) continue;
+                if (first) {
+#pragma unroll
+                    for (int o = 0; o < CH; ++o) {
+                        const float g = SRC.direct.gains[c][o];
+                        if (o < channels && audible(g)) out[o] += in[c] * g;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = SRC.aux[slot].gains[c][k];
+                    if (audible(g)) wet[k] += in[c] * g;
+                }
+            }
+            if (!first && act) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < channels) out[c] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
+            }
+            float a[4];
+            a[0] = 0.0F; a[0] += wet[0] * b2a; a[0] += wet[1] * b2a; a[0] += wet[2] * b2a; a[0] += wet[3] * b2a;
+            a[1] = 0.0F; a[1] += wet[0] * b2a; a[1] += wet[1] * -b2a; a[1] += wet[2] * -b2a; a[1] += wet[3] * b2a;
+            a[2] = 0.0F; a[2] += wet[0] * b2a; a[2] += wet[1] * b2a; a[2] += wet[2] * -b2a; a[2] += wet[3] * -b2a;
+            a[3] = 0.0F; a[3] += wet[0] * b2a; a[3] += wet[1] * -b2a; a[3] += wet[2] * b2a; a[3] += wet[3] * -b2a;
+
+            // ---------------- input shelves (reference src/oalsfxpp.cpp:7867-7879) ----------------
+            if (act) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) row(0, c)[4 + lane] = a[c];
+            }
+            wave_sync();
+            if (act) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* x = row(0, c) + 4 + lane;
+                    row(3, c)[4 + lane] = (P.lp.b0 * x[0]) + (P.lp.b1 * x[-1]) + (P.lp.b2 * x[-2]);
+                }
+            }
+            wave_sync();
+            if (lane < 4) {
+                biquad_chain(row(3, lane), row(1, lane), L, P.lp.a1, P.lp.a2);
+            }
+            wave_sync();
+            float xin[4];
+            if (eax) {
+                if (act) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* x = row(1, c) + 4 + lane;
+                        row(3, c)[4 + lane] = (P.hp.b0 * x[0]) + (P.hp.b1 * x[-1]) + (P.hp.b2 * x[-2]);
+                    }
+                }
+                wave_sync();
+                if (lane < 4) biquad_chain(row(3, lane), row(2, lane), L, P.hp.a1, P.hp.a2);
+                wave_sync();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xin[c] = row(2, c)[4 + lane];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xin[c] = row(1, c)[4 + lane];
+            }
+            wave_sync();
+            if (lane < 4) {
+                roll_history(row(0, lane), L);
+                roll_history(row(1, lane), L);
+                if (eax) roll_history(row(2, lane), L);
+            }
+            if (act) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ring[OALSFX_RV_MAIN].line(c)[t & ring[OALSFX_RV_MAIN].mask] = xin[c];
+            }
+            mem_sync();
+
+            // ---------------- early reflections (reference src/oalsfxpp.cpp:7625-7672) ----------------
+            float f[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+            for (int sb = 0; sb < L;) {
+                const int s = min(L - sb, eap_limit);
+                if (act && lane >= sb && lane < sb + s) {
+                    float g[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        f[j] = tap(ring[OALSFX_RV_MAIN], j, faded, t - cur_etap[j], t - new_etap[j], fade) * P.early_tap_coeff[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float input = f[j];
+                        f[j] = tap(ring[OALSFX_RV_EARLY_AP], j, faded, t - cur_eap[j], t - new_eap[j], fade) - (apc * input);
+                        g[j] = input + (apc * f[j]);
+                    }
+                    scatter(g, mx, my);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_EARLY_AP].line(j)[t & ring[OALSFX_RV_EARLY_AP].mask] = g[j];
+                }
+                sb += s;
+                if (sb < L) mem_sync();
+            }
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ring[OALSFX_RV_EARLY_LINE].line(j)[t & ring[OALSFX_RV_EARLY_LINE].mask] = f[3 - j];
+            }
+            mem_sync();
+            float early[4];
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    f[j] += tap(ring[OALSFX_RV_EARLY_LINE], j, faded, t - cur_eline[j], t - new_eline[j], fade) * P.early_line_coeff[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) early[j] = f[j];
+            {
+                float v[4] = {f[3], f[2], f[1], f[0]};
+                scatter(v, mx, my);
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_MAIN].line(j)[(t - P.late_feed_tap) & ring[OALSFX_RV_MAIN].mask] = v[j];
+                }
+            }
+            mem_sync();
+
+            // ---------------- late reverb (reference src/oalsfxpp.cpp:7735-7794) ----------------
+            int md = 0;
+            if (mod_active && act) {
+                int index = mod_index + done + lane;
+                index %= mod_range;
+                const float sinus = glibc_sinf(6.28318530717958647692F * index / mod_range);
+                md = lround_away(rng[done + lane] * sinus);
+            }
+            float late[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+            for (int sb = 0; sb < L;) {
+                // sub-block: lanes whose late-line feedback reads stay outside the sub-block
+                const int rel = lane - sb;
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d0 = cur_lline[j] + md;
+                    ok &= (d0 > rel) || (d0 <= 0);
+                    if (faded) {
+                        const int d1 = new_lline[j] + md;
+                        ok &= (d1 > rel) || (d1 <= 0);
+                    }
+                }
+                const unsigned long long okm = __ballot(ok || !act || lane < sb) >> sb;
+                const int lead = (~okm == 0ULL) ? 64 : __builtin_ctzll(~okm);
+                const int s = min(min(L - sb, lap_limit), lead);
+                const bool on = act && lane >= sb && lane < sb + s;
+                if (on) {
+                    const int td = t - md;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = tap(ring[OALSFX_RV_MAIN], j, faded, t - cur_ltap[j], t - new_ltap[j], fade) * P.density_gain;
+                        v += tap(ring[OALSFX_RV_LATE_LINE], j, faded, td - cur_lline[j], td - new_lline[j], fade);
+                        row(3, j)[4 + lane] = v;
+                    }
+                }
+                wave_sync();
+                if (lane < 4) {
+                    // two first-order sections and the mid gain (reference src/oalsfxpp.cpp:7691-7719)
+                    float* u = row(3, lane) + 4;
+                    const float l0 = P.t60_lf[lane][0], l1 = P.t60_lf[lane][1], l2 = P.t60_lf[lane][2];
+                    const float h0 = P.t60_hf[lane][0], h1 = P.t60_hf[lane][1], h2 = P.t60_hf[lane][2];
+                    const float mid = P.t60_mid[lane];
+                    for (int i = sb; i < sb + s; ++i) {
+                        const float x = u[i];
+                        const float o1 = (l0 * x) + (l1 * t60_s00) + (l2 * t60_s01);
+                        t60_s00 = x;
+                        t60_s01 = o1;
+                        const float o2 = (h0 * o1) + (h1 * t60_s10) + (h2 * t60_s11);
+                        t60_s10 = o1;
+                        t60_s11 = o2;
+                        u[i] = mid * o2;
+                    }
+                }
+                wave_sync();
+                if (on) {
+                    float v[4], g[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float input = row(3, j)[4 + lane];
+                        v[j] = tap(ring[OALSFX_RV_LATE_AP], j, faded, t - cur_lap[j], t - new_lap[j], fade) - (apc * input);
+                        g[j] = input + (apc * v[j]);
+                    }
+                    scatter(g, mx, my);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ring[OALSFX_RV_LATE_AP].line(j)[t & ring[OALSFX_RV_LATE_AP].mask] = g[j];
+                        late[j] = v[j];
+                    }
+                    float r[4] = {v[3], v[2], v[1], v[0]};
+                    scatter(r, mx, my);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_LATE_LINE].line(j)[t & ring[OALSFX_RV_LATE_LINE].mask] = r[j];
+                }
+                sb += s;
+                if (sb < L) mem_sync();
+            }
+
+            // ---------------- pan to the outputs with gain ramps (reference src/oalsfxpp.cpp:6142-6166) ----------------
+            if (ramp_mask != 0ULL) {
+                if (g_ramp) {
+                    float* gs = gseq + lane * 64;
+                    for (int i = 0; i < L; ++i) {
+                        gs[i] = g_run;
+                        g_run += g_step;
+                    }
+                }
+                wave_sync();
+            }
+#pragma unroll
+            for (int stage = 0; stage < 2; ++stage) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float data = stage ? late[j] : early[j];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (c >= channels) continue;
+                        const int q = (stage * 4 + j) * CH + c;
+                        if ((ramp_mask >> q) & 1ULL) {
+                            out[c] += data * gseq[q * 64 + lane];
+                        } else {
+                            const float gq = __shfl(g_cur, q);
+                            if (audible(gq)) out[c] += data * gq;
+                        }
+                    }
+                }
+            }
+            if (ramp_mask != 0ULL) wave_sync();
+
+            if (act) {
+                if (last) {
+                    if (CH == 2) {
+                        *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(out[0], out[CH - 1]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c)
+                            if (c < channels) dst[static_cast<size_t>(pos) * channels + c] = out[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if (c < channels) mixbuf[c * OALSFX_MAX_CHUNK + pos] = out[c];
+                }
+            }
+        } // tiles
+
+        // ---- chunk epilogue ----
+        if (mod_active) mod_filter = rng[todo - 1];
+        mod_index = (mod_index + todo) % mod_range;
+        offset += todo;
+        if (fade_count < OALSFX_RV_FADE_SAMPLES) {
+            fade_count += todo;
+            if (fade_count >= OALSFX_RV_FADE_SAMPLES) {
+                fade_count = OALSFX_RV_FADE_SAMPLES;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cur_etap[j] = new_etap[j]; cur_eap[j] = new_eap[j]; cur_eline[j] = new_eline[j];
+                    cur_ltap[j] = new_ltap[j]; cur_lap[j] = new_lap[j]; cur_lline[j] = new_lline[j];
+                }
+            }
+        }
+        if (g_ramp) g_cur = (todo == counter) ? g_tgt : g_run;
+        wave_sync();
+        base += todo;
+    }
+
+    // ---- write the state back ----
+    wave_sync();
+    if (lane < 4) {
+        const float* r0 = row(0, lane); const float* r1 = row(1, lane); const float* r2 = row(2, lane);
+        S.lp[lane].x[0] = r0[3]; S.lp[lane].x[1] = r0[2];
+        S.lp[lane].y[0] = r1[3]; S.lp[lane].y[1] = r1[2];
+        if (eax) {
+            S.hp[lane].x[0] = r1[3]; S.hp[lane].x[1] = r1[2];
+            S.hp[lane].y[0] = r2[3]; S.hp[lane].y[1] = r2[2];
+        }
+        S.t60[lane][0][0] = t60_s00; S.t60[lane][0][1] = t60_s01;
+        S.t60[lane][1][0] = t60_s10; S.t60[lane][1][1] = t60_s11;
+    }
+    if (q_valid) {
+        if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
+        else S.early_cur_gain[q_line][q_chan] = g_cur;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            S.cur_early_tap[j] = cur_etap[j]; S.cur_early_ap_off[j] = cur_eap[j]; S.cur_early_line_off[j] = cur_eline[j];
+            S.cur_late_tap[j] = cur_ltap[j]; S.cur_late_ap_off[j] = cur_lap[j]; S.cur_late_line_off[j] = cur_lline[j];
+        }
+        S.mod_index = mod_index; S.mod_range = mod_range; S.mod_filter = mod_filter;
+        S.fade_count = fade_count; S.offset = offset;
+        SS.seen_seq = SP.update_seq;
+    }
+    if (first && lane < channels) {
+        // last two input frames of the stream (pass-through history of the send filters)
+        float* tail = ctx.src_tail + (static_cast<size_t>(inst) * channels + lane) * 2;
+        if (frames >= 2) {
+            tail[0] = src[static_cast<size_t>(frames - 1) * channels + lane];
+            tail[1] = src[static_cast<size_t>(frames - 2) * channels + lane];
+        } else if (frames == 1) {
+            tail[1] = tail[0];
+            tail[0] = src[lane];
+        }
+    }
+}
+
+void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)
+{
+    if (count <= 0) return;
+    const dim3 grid((count + 3) / 4), block(256);
+    if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
+    else if (ctx.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
+    else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, ctx, slot, list, count, flags);
+}
+
+} // namespace oalsfx_hip

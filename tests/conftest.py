@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """The product library and the CPU oracle must exist; build them if the tree is fresh."""
+    from oalsfxpp_amd import build, lib
+    if not os.path.exists(lib.LIB_PATH):
+        build.build_all()
+    from oracle import oracle as orc
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        orc.build(ref=os.path.isdir("/root/reference"))
+    yield

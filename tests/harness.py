@@ -146,3 +146,45 @@ def struct_diff(a, b, path=""):
         if not same:
             out.append(f"{path}: {a!r} != {b!r}")
     return out
+
+
+class OracleShadow:
+    """CPU oracle that follows one instance of a `Batch`: it is fed the descriptors the batch derived
+    (read back through the C ABI), so outputs, states and rings can be compared word for word."""
+
+    def __init__(self, batch, instance):
+        self.batch, self.instance = batch, instance
+        self.oracle = orc.Oracle(batch.channels, batch.effect_count)
+        self.seq = [None] * batch.effect_count
+        self.types = [None] * batch.effect_count
+        self.source_raw = None
+
+    def sync(self):
+        for s in range(self.batch.effect_count):
+            p, _ = self.batch.read_slot(self.instance, s)
+            if self.seq[s] != p.update_seq:
+                self.oracle.set_slot(s, p, restart=(self.types[s] != p.type))
+                self.seq[s], self.types[s] = p.update_seq, p.type
+        sp, _ = self.batch.read_source(self.instance)
+        if bytes(sp) != self.source_raw:
+            self.oracle.set_source(sp)
+            self.source_raw = bytes(sp)
+
+    def mix(self, src):
+        self.sync()
+        return self.oracle.mix(src)
+
+    def compare_state(self):
+        """Differences between the batch's device state / rings and the oracle's, as strings."""
+        diffs = []
+        for s in range(self.batch.effect_count):
+            p, st = self.batch.read_slot(self.instance, s)
+            if p.type in desc.STATE_MEMBER:
+                m = desc.STATE_MEMBER[p.type]
+                diffs += struct_diff(getattr(st.u, m), getattr(self.oracle.state(s).u, m), f"slot{s}.{m}")
+            ring_gpu = self.batch.read_ring(self.instance, s)
+            ring_cpu = self.oracle.ring(s)
+            if ring_gpu.tobytes() != ring_cpu.tobytes():
+                bad = np.nonzero(ring_gpu.view(np.uint32) != ring_cpu.view(np.uint32))[0] if ring_gpu.size == ring_cpu.size else []
+                diffs.append(f"slot{s}.ring: {len(bad)} words differ (sizes {ring_gpu.size}/{ring_cpu.size}), first {list(bad[:4])}")
+        return diffs

@@ -1,0 +1,136 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bit-exact (outputs, effect state, delay rings) -- stricter than the 1e-5 relative tolerance
+BASELINE.json allows, because every kernel keeps the reference's arithmetic order.
+"""
+import numpy as np
+import pytest
+
+from harness import OracleShadow, make_effect, preset_effect
+from oalsfxpp_amd import desc
+from oalsfxpp_amd.api import Batch
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+E = make_effect
+
+
+def run_batch(fmt, rate, slots, setups, script, check_instances=None):
+    """setups: per instance, list of (slot, effect).  script: list of ('mix', frames) / ('set', inst, slot, effect) / ('apply',)"""
+    n = len(setups)
+    with Batch(n, fmt, rate, slots) as b:
+        for i, eff in enumerate(setups):
+            for slot, e in eff:
+                b.set_effect(slot, e, first=i, count=1)
+        b.apply_changes()
+        check = list(range(n)) if check_instances is None else check_instances
+        shadows = {i: OracleShadow(b, i) for i in check}
+        k = 0
+        for op in script:
+            if op[0] == "set":
+                b.set_effect(op[2], op[3], first=op[1], count=1)
+            elif op[0] == "apply":
+                b.apply_changes()
+            else:
+                frames = op[1]
+                x = np.stack([orc.synth(1000 + i, k, frames * b.channels).reshape(frames, b.channels) for i in range(n)])
+                y = b.mix(x)
+                for i in check:
+                    ref = shadows[i].mix(x[i])
+                    assert y[i].tobytes() == ref.tobytes(), (
+                        f"instance {i} buffer {k}: max |diff| {np.abs(y[i] - ref).max():.3g}, "
+                        f"{np.count_nonzero(y[i] != ref)} of {ref.size} samples differ")
+                k += 1
+        for i in check:
+            d = shadows[i].compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:6])
+
+
+def test_eax_reverb_defaults_stereo():
+    run_batch(desc.FMT_STEREO, 48000, 1, [[(0, E(desc.EAX_REVERB))]] * 5, [("mix", 256)] * 10)
+
+
+def test_eax_reverb_defaults_mono():
+    run_batch(desc.FMT_MONO, 48000, 1, [[(0, E(desc.EAX_REVERB))]] * 3, [("mix", 256)] * 8)
+
+
+def test_reverb_plain():
+    run_batch(desc.FMT_STEREO, 48000, 1, [[(0, E(desc.REVERB))], [(0, preset_effect(25, desc.REVERB))]], [("mix", 256)] * 8)
+
+
+def test_eax_presets():
+    setups = [[(0, preset_effect(i))] for i in range(0, 113)]
+    run_batch(desc.FMT_STEREO, 48000, 1, setups, [("mix", 256)] * 6)
+
+
+def test_eax_extremes_and_modulation():
+    a = E(desc.EAX_REVERB, modulation_depth=1.0, modulation_time=0.04, echo_depth=0.7, echo_time=0.08, density=0.0, diffusion=0.3,
+          reflections_delay=0.0, late_reverb_delay=0.0, gain_lf=0.3, reflections_pan=[0.3, -0.2, 0.5], late_reverb_pan=[-0.6, 0.1, -0.4],
+          decay_hf_limit=False, decay_hf_ratio=2.0, decay_lf_ratio=0.3)
+    bb = E(desc.EAX_REVERB, reflections_delay=0.3, density=1.0, late_reverb_delay=0.1, modulation_depth=0.5, modulation_time=4.0,
+           decay_time=20.0, decay_lf_ratio=2.0, decay_hf_ratio=0.1)
+    c = E(desc.EAX_REVERB, density=0.0, diffusion=1.0, modulation_depth=1.0, modulation_time=0.25)
+    run_batch(desc.FMT_STEREO, 48000, 1, [[(0, a)], [(0, bb)], [(0, c)]], [("mix", 256)] * 12)
+
+
+def test_eax_midstream_change_and_odd_sizes():
+    script = [("mix", 256)] * 4 + [("set", 0, 0, preset_effect(8)), ("set", 1, 0, preset_effect(112)), ("apply",)] + [("mix", 256)] * 3
+    script += [("mix", 100), ("mix", 1), ("mix", 2), ("mix", 127), ("mix", 129), ("mix", 3000), ("mix", 2048), ("mix", 2049)]
+    run_batch(desc.FMT_STEREO, 48000, 1, [[(0, E(desc.EAX_REVERB))], [(0, preset_effect(3))]], script)
+
+
+def test_eax_low_and_high_rates():
+    for rate in (8000, 11025, 22050, 96000):
+        run_batch(desc.FMT_STEREO, rate, 1, [[(0, E(desc.EAX_REVERB))], [(0, preset_effect(112))], [(0, E(desc.EAX_REVERB, density=0.0, modulation_depth=1.0))]],
+                  [("mix", 256)] * 6)
+
+
+@pytest.mark.parametrize("etype", [desc.NULL, desc.CHORUS, desc.COMPRESSOR, desc.DEDICATED_DIALOG, desc.DEDICATED_LFE, desc.DISTORTION,
+                                   desc.ECHO, desc.EQUALIZER, desc.FLANGER, desc.RING_MODULATOR])
+def test_simple_effect_defaults(etype):
+    for fmt in (desc.FMT_MONO, desc.FMT_STEREO):
+        run_batch(fmt, 48000, 1, [[(0, E(etype))]] * 2, [("mix", 256)] * 6 + [("mix", 77)])
+
+
+def test_simple_effect_variants():
+    setups = []
+    for w in (0, 1):
+        for ph in (-180, -90, 0, 90, 180):
+            setups.append([(0, E(desc.CHORUS, waveform=w, phase=ph, rate=7.3, depth=0.9, feedback=-0.8, delay=0.011))])
+            setups.append([(0, E(desc.FLANGER, waveform=w, phase=ph, rate=3.1, depth=1.0, feedback=0.9, delay=0.004))])
+    setups.append([(0, E(desc.FLANGER, rate=0.0, delay=0.0))])
+    for wv in (0, 1, 2):
+        setups.append([(0, E(desc.RING_MODULATOR, waveform=wv, frequency=1234.5, high_pass_cutoff=3000.0))])
+    setups.append([(0, E(desc.COMPRESSOR, on_off=False))])
+    for sp in (-1.0, -0.4, 0.0, 0.6, 1.0):
+        setups.append([(0, E(desc.ECHO, spread=sp, delay=0.01, lr_delay=0.02, damping=0.9, feedback=0.95))])
+    setups.append([(0, E(desc.ECHO, delay=0.0, lr_delay=0.0))])
+    for ed in (0.0, 0.5, 1.0):
+        setups.append([(0, E(desc.DISTORTION, edge=ed, gain=1.0, low_pass_cutoff=24000.0, eq_center=80.0, eq_bandwidth=24000.0))])
+    setups.append([(0, E(desc.EQUALIZER, low_gain=7.943, low_cutoff=50.0, mid1_gain=0.126, mid1_width=0.01, mid2_gain=7.0, mid2_center=8000.0,
+                         high_gain=0.126, high_cutoff=16000.0))])
+    run_batch(desc.FMT_STEREO, 48000, 1, setups, [("mix", 256)] * 8)
+
+
+def test_four_slots_config3():
+    chain = [(0, E(desc.CHORUS)), (1, E(desc.FLANGER)), (2, E(desc.ECHO)), (3, E(desc.EAX_REVERB))]
+    run_batch(desc.FMT_STEREO, 48000, 4, [chain] * 3, [("mix", 256)] * 8)
+
+
+def test_mixed_types_config4():
+    setups = [[(0, E(1 + i % 11))] for i in range(44)]
+    run_batch(desc.FMT_STEREO, 48000, 1, setups, [("mix", 256)] * 6)
+
+
+def test_mixed_slots_with_nulls_and_type_changes():
+    setups = [[(0, E(desc.NULL)), (1, E(desc.ECHO)), (2, E(desc.NULL))], [(0, E(desc.EAX_REVERB)), (1, E(desc.NULL)), (2, E(desc.EQUALIZER))],
+              [(0, E(desc.NULL)), (1, E(desc.NULL)), (2, E(desc.NULL))]]
+    script = [("mix", 256)] * 3 + [("set", 0, 1, E(desc.EAX_REVERB)), ("set", 1, 0, E(desc.ECHO)), ("apply",)] + [("mix", 256)] * 3
+    run_batch(desc.FMT_STEREO, 48000, 3, setups, script)
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_5POINT1_REAR, desc.FMT_6POINT1, desc.FMT_7POINT1])
+def test_other_channel_formats(fmt):
+    setups = [[(0, E(t))] for t in (desc.EAX_REVERB, desc.CHORUS, desc.ECHO, desc.EQUALIZER, desc.DEDICATED_DIALOG, desc.COMPRESSOR)]
+    run_batch(fmt, 44100, 1, setups, [("mix", 200)] * 3)
