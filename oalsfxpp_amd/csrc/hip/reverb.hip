@@ -123,7 +123,7 @@ __device__ __forceinline__ void roll_history(float* row, int n)
 } // namespace
 
 template <int CH>
-__global__ __launch_bounds__(256) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     constexpr int NQ = Lds<CH>::kChains;
     __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];

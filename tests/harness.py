@@ -127,6 +127,17 @@ class OracleApi:
         return self.oracle.mix(src)
 
 
+def same_bits(a, b):
+    """Bit-exact comparison of two float32 arrays; NaNs compare equal whatever their sign/payload
+    (x86 and gfx950 encode the default NaN differently)."""
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    b = np.ascontiguousarray(b, dtype=np.float32).reshape(-1)
+    if a.size != b.size:
+        return False, a.size
+    bad = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+    return not bad.any(), int(bad.sum())
+
+
 def noise(seed, frames, channels):
     """Deterministic uniform [-1, 1) test signal (the benchmark generator)."""
     return orc.synth(seed, 0, frames * channels).reshape(frames, channels)
@@ -142,7 +153,7 @@ def struct_diff(a, b, path=""):
         for i in range(len(a)):
             out += struct_diff(a[i], b[i], f"{path}[{i}]")
     else:
-        same = (a == b) or (isinstance(a, float) and np.float32(a).tobytes() == np.float32(b).tobytes())
+        same = (a == b) or (isinstance(a, float) and (np.float32(a).tobytes() == np.float32(b).tobytes() or (a != a and b != b)))
         if not same:
             out.append(f"{path}: {a!r} != {b!r}")
     return out
@@ -184,7 +195,7 @@ class OracleShadow:
                 diffs += struct_diff(getattr(st.u, m), getattr(self.oracle.state(s).u, m), f"slot{s}.{m}")
             ring_gpu = self.batch.read_ring(self.instance, s)
             ring_cpu = self.oracle.ring(s)
-            if ring_gpu.tobytes() != ring_cpu.tobytes():
-                bad = np.nonzero(ring_gpu.view(np.uint32) != ring_cpu.view(np.uint32))[0] if ring_gpu.size == ring_cpu.size else []
-                diffs.append(f"slot{s}.ring: {len(bad)} words differ (sizes {ring_gpu.size}/{ring_cpu.size}), first {list(bad[:4])}")
+            ok, nbad = same_bits(ring_gpu, ring_cpu)
+            if not ok:
+                diffs.append(f"slot{s}.ring: {nbad} words differ (sizes {ring_gpu.size}/{ring_cpu.size})")
         return diffs
