@@ -89,12 +89,10 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from oalsfxpp_amd import desc, lib
+    from oalsfxpp_amd import desc, lib, sharding
     from oalsfxpp_amd.api import Batch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = sharding.env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
@@ -132,9 +130,8 @@ def main():
         step(k)
     batch.synchronize()
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
 
     batch.kernel_timing(True)
     t0 = time.perf_counter()
@@ -143,12 +140,9 @@ def main():
     batch.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        dist.barrier()
-        torch.cuda.synchronize()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    sharding.barrier()
+    torch.cuda.synchronize()
+    elapsed = sharding.max_over_ranks(elapsed, device="cuda")
 
     launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
     batch.kernel_timing(False)

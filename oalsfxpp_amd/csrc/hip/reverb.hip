@@ -12,6 +12,9 @@
 //     A-format vector of its sample in registers, so the scattering matrices are register math;
 //   * every delay ring is stored per line (line j of ring r is one contiguous power-of-two ring), so
 //     a tap read or a ring write of a tile is one contiguous 256-byte wave access;
+//   * in the steady state (no cross-fade) every tap whose delay keeps it outside the tile is loaded at
+//     the top of the tile, before any arithmetic: one HBM round trip per tile, hidden behind the
+//     input-shelf recurrences;
 //   * feedback paths (the two vector all-passes, the modulated late line) are honoured by cutting a
 //     tile into sub-blocks no longer than the shortest positive feedback delay (23+ samples at
 //     48 kHz, so usually the whole tile); a delay of 0 in a feedback ring reads the slot before it is
@@ -19,6 +22,9 @@
 //   * the second-order input shelves and the first-order T60 sections are serial recurrences that
 //     must round exactly like the reference: their feed-forward half is evaluated per lane, the
 //     feedback half runs on 4 "chain" lanes (one per line) over the tile via an LDS transpose.
+//
+// Ordering of ring stores and later tap loads inside one wavefront relies on the hardware executing a
+// wavefront's memory instructions in order; the wavefront-scope fences below only pin the compiler.
 //
 // Bit-exactness: compiled with -ffp-contract=off; expression association follows the reference.
 #include <float.h>
@@ -30,34 +36,26 @@ namespace oalsfx_hip {
 namespace {
 
 constexpr int kRow = 68;          // 4 (history prefix, 16-byte aligned data) + 64 samples
-constexpr int kRows = 4 * 4;      // 4 row groups x 4 lines
+constexpr int kGroups = 3;        // row groups, 4 lines each
 constexpr int kRngFloats = OALSFX_RV_MAX_UPDATE;
 
 template <int CH>
 struct Lds {
     static constexpr int kChains = 8 * CH; // (early|late) x 4 lines x channels gain ramps
-    static constexpr int kFloats = kRows * kRow + kRngFloats + kChains * 64;
+    static constexpr int kFloats = kGroups * 4 * kRow + kRngFloats + kChains * 64;
 };
 
+// Hand-off between lanes of one wavefront through LDS or through the rings in global memory:
+// pins the compiler; the hardware keeps one wavefront's memory operations in program order.
 __device__ __forceinline__ void wave_sync()
 {
-    // LDS hand-off between lanes of one wavefront: order the compiler, the hardware keeps a wave's
-    // LDS operations in order.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void mem_sync()
-{
-    // ring stores of this wavefront must be complete before later tap loads of other lanes
-    // (same CU, same L1: workgroup scope is sufficient and costs one s_waitcnt vmcnt(0))
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 __device__ __forceinline__ int min_positive(int limit, int d) { return (d > 0 && d < limit) ? d : limit; }
+__device__ __forceinline__ int min4(const int v[4]) { return min(min(v[0], v[1]), min(v[2], v[3])); }
 
 struct Ring {
     float* base; // line 0
@@ -86,11 +84,10 @@ __device__ __forceinline__ void scatter(float v[4], float x, float y)
     v[3] = (x * f3) + (y * (-f0 + -f1 + -f2));
 }
 
-// Serial half of a biquad over `n` samples of one LDS row: y = (u - a1*y1) - a2*y2.
-// in: row_u[4+i] = feed-forward sums; out: row_y[4+i]; row_y[3], row_y[2] hold y[-1], y[-2].
-__device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, int n, float a1, float a2)
+// Serial half of a biquad over samples [0, n) of one LDS row: y = (u - a1*y1) - a2*y2.
+// row_u[4+i] holds the feed-forward sums, row_y[4+i] receives the outputs.
+__device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, int n, float a1, float a2, float& y1, float& y2)
 {
-    float y1 = row_y[3], y2 = row_y[2];
     int i = 0;
     for (; i + 4 <= n; i += 4) {
         const float4 u = *reinterpret_cast<const float4*>(row_u + 4 + i);
@@ -111,13 +108,28 @@ __device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, i
     }
 }
 
-// After a tile of n samples the last two entries become the history prefix of the next tile.
-__device__ __forceinline__ void roll_history(float* row, int n)
+// Serial half of a first-order section over samples [lo, hi): o = u + c2*o_prev; stores scale*o.
+__device__ __forceinline__ void first_order_chain(const float* row_u, float* row_o, int lo, int hi, float c2, float scale, bool scaled, float& prev)
 {
-    const float a = row[4 + n - 2]; // n == 1 reads row[3], the previous newest sample
-    const float b = row[4 + n - 1];
-    row[2] = a;
-    row[3] = b;
+    int i = lo;
+    if ((lo & 3) == 0) {
+        for (; i + 4 <= hi; i += 4) {
+            const float4 u = *reinterpret_cast<const float4*>(row_u + 4 + i);
+            float4 o;
+            o.x = u.x + (c2 * prev);
+            o.y = u.y + (c2 * o.x);
+            o.z = u.z + (c2 * o.y);
+            o.w = u.w + (c2 * o.z);
+            prev = o.w;
+            if (scaled) { o.x = scale * o.x; o.y = scale * o.y; o.z = scale * o.z; o.w = scale * o.w; }
+            *reinterpret_cast<float4*>(row_o + 4 + i) = o;
+        }
+    }
+    for (; i < hi; ++i) {
+        const float o = row_u[4 + i] + (c2 * prev);
+        prev = o;
+        row_o[4 + i] = scaled ? scale * o : o;
+    }
 }
 
 } // namespace
@@ -134,9 +146,8 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     const int lane = threadIdx.x & 63;
 
     float* lds = lds_all[wave_in_block];
-    // row groups: 0 = A-format input (lp x), 1 = lp output (lp y, hp x), 2 = hp output (hp y), 3 = scan scratch (u / T60)
     auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
-    float* rng = lds + kRows * kRow;
+    float* rng = lds + kGroups * 4 * kRow;
     float* gseq = rng + kRngFloats;
 
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
@@ -160,18 +171,20 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
         ring[r].len = P.ring_len[r];
         ring[r].mask = P.ring_len[r] - 1;
     }
+    const Ring& r_main = ring[OALSFX_RV_MAIN];
+    const Ring& r_eap = ring[OALSFX_RV_EARLY_AP];
+    const Ring& r_eline = ring[OALSFX_RV_EARLY_LINE];
+    const Ring& r_lap = ring[OALSFX_RV_LATE_AP];
+    const Ring& r_lline = ring[OALSFX_RV_LATE_LINE];
 
     // ---- instance state into registers (all wave-uniform) ----
     int fade_count = S.fade_count, offset = S.offset, mod_index = S.mod_index, mod_range = S.mod_range;
     float mod_filter = S.mod_filter;
     int cur_etap[4], cur_eap[4], cur_eline[4], cur_ltap[4], cur_lap[4], cur_lline[4];
-    int new_etap[4], new_eap[4], new_eline[4], new_ltap[4], new_lap[4], new_lline[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         cur_etap[j] = S.cur_early_tap[j]; cur_eap[j] = S.cur_early_ap_off[j]; cur_eline[j] = S.cur_early_line_off[j];
         cur_ltap[j] = S.cur_late_tap[j]; cur_lap[j] = S.cur_late_ap_off[j]; cur_lline[j] = S.cur_late_line_off[j];
-        new_etap[j] = P.early_tap[j]; new_eap[j] = P.early_ap_off[j]; new_eline[j] = P.early_line_off[j];
-        new_ltap[j] = P.late_tap[j]; new_lap[j] = P.late_ap_off[j]; new_lline[j] = P.late_line_off[j];
     }
 
     // pending parameter update: what do_update does to state (reference src/oalsfxpp.cpp:7028-7031, 6062-6075)
@@ -181,23 +194,18 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
         bool differ = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            differ |= (new_etap[j] != cur_etap[j]) | (new_eap[j] != cur_eap[j]) | (new_eline[j] != cur_eline[j]) |
-                      (new_ltap[j] != cur_ltap[j]) | (new_lap[j] != cur_lap[j]) | (new_lline[j] != cur_lline[j]);
+            differ |= (P.early_tap[j] != cur_etap[j]) | (P.early_ap_off[j] != cur_eap[j]) | (P.early_line_off[j] != cur_eline[j]) |
+                      (P.late_tap[j] != cur_ltap[j]) | (P.late_ap_off[j] != cur_lap[j]) | (P.late_line_off[j] != cur_lline[j]);
         if (differ) fade_count = 0;
     }
 
-    // ---- chain lanes: filter histories into the LDS row prefixes ----
-    if (lane < 4) {
-        float* r0 = row(0, lane); float* r1 = row(1, lane); float* r2 = row(2, lane);
-        r0[3] = S.lp[lane].x[0]; r0[2] = S.lp[lane].x[1];
-        r1[3] = S.lp[lane].y[0]; r1[2] = S.lp[lane].y[1];
-        r2[3] = S.hp[lane].y[0]; r2[2] = S.hp[lane].y[1];
-    }
-    float t60_s00 = 0.f, t60_s01 = 0.f, t60_s10 = 0.f, t60_s11 = 0.f;
-    if (lane < 4) {
-        t60_s00 = S.t60[lane][0][0]; t60_s01 = S.t60[lane][0][1];
-        t60_s10 = S.t60[lane][1][0]; t60_s11 = S.t60[lane][1][1];
-    }
+    // ---- chain lanes (0..3, one per line): filter histories in registers ----
+    const int cl = lane & 3;
+    float lpx0 = S.lp[cl].x[0], lpx1 = S.lp[cl].x[1], lpy0 = S.lp[cl].y[0], lpy1 = S.lp[cl].y[1];
+    float hpy0 = S.hp[cl].y[0], hpy1 = S.hp[cl].y[1];
+    float t60_x = S.t60[cl][0][0], t60_o1 = S.t60[cl][0][1], t60_o1b = S.t60[cl][1][0], t60_o2 = S.t60[cl][1][1];
+    const float lp_a1 = P.lp.a1, lp_a2 = P.lp.a2, hp_a1 = P.hp.a1, hp_a2 = P.hp.a2;
+    const float t_l2 = P.t60_lf[cl][2], t_h2 = P.t60_hf[cl][2], t_mid = P.t60_mid[cl];
 
     // ---- chain lanes: output gain ramps. chain q = (stage*4 + line)*CH + channel ----
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
@@ -248,10 +256,18 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             eap_limit = min_positive(eap_limit, cur_eap[j]);
             lap_limit = min_positive(lap_limit, cur_lap[j]);
             if (faded) {
-                eap_limit = min_positive(eap_limit, new_eap[j]);
-                lap_limit = min_positive(lap_limit, new_lap[j]);
+                eap_limit = min_positive(eap_limit, P.early_ap_off[j]);
+                lap_limit = min_positive(lap_limit, P.late_ap_off[j]);
             }
         }
+        // steady state: which tap groups lie entirely before a full tile and can be fetched up front
+        const bool pre = !faded;
+        const bool pre_e = pre && min4(cur_etap) >= 64;
+        const bool pre_a = pre && min4(cur_eap) >= 64;
+        const bool pre_el = pre && min4(cur_eline) >= 64;
+        const bool pre_lt = pre && min4(cur_ltap) >= P.late_feed_tap + 64;
+        const bool pre_la = pre && min4(cur_lap) >= 64;
+        const bool pre_ll = pre_la && !mod_active && min4(cur_lline) >= 64;
 
         for (int done = 0; done < todo; done += 64) {
             const int L = min(64, todo - done);
@@ -260,7 +276,9 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             const int pos = base + done + lane;                 // index inside the caller's chunk
             const float fade = static_cast<float>(fade_count + done + lane) * (1.0F / OALSFX_RV_FADE_SAMPLES);
 
-            // ---------------- input: source frame -> dry mix, B-format send, A-format ----------------
+            wave_sync(); // ring stores of the previous tile precede the loads below (program order)
+
+            // ---------------- loads that do not depend on this tile ----------------
             float in[CH];
             float out[CH];
 #pragma unroll
@@ -275,6 +293,26 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                         if (c < channels) in[c] = src[static_cast<size_t>(pos) * channels + c];
                 }
             }
+            float p_e[4], p_a[4], p_el[4], p_lt[4], p_ll[4], p_la[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p_e[j] = p_a[j] = p_el[j] = p_lt[j] = p_ll[j] = p_la[j] = 0.0F;
+                if (act) {
+                    if (pre_e) p_e[j] = r_main.line(j)[(t - cur_etap[j]) & r_main.mask];
+                    if (pre_a) p_a[j] = r_eap.line(j)[(t - cur_eap[j]) & r_eap.mask];
+                    if (pre_el) p_el[j] = r_eline.line(j)[(t - cur_eline[j]) & r_eline.mask];
+                    if (pre_lt) p_lt[j] = r_main.line(j)[(t - cur_ltap[j]) & r_main.mask];
+                    if (pre_ll) p_ll[j] = r_lline.line(j)[(t - cur_lline[j]) & r_lline.mask];
+                    if (pre_la) p_la[j] = r_lap.line(j)[(t - cur_lap[j]) & r_lap.mask];
+                }
+            }
+            if (!first && act) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < channels) out[c] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
+            }
+
+            // ---------------- input: source frame -> dry mix, B-format send, A-format ----------------
             float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -292,11 +330,6 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     if (audible(g)) wet[k] += in[c] * g;
                 }
             }
-            if (!first && act) {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < channels) out[c] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
-            }
             float a[4];
             a[0] = 0.0F; a[0] += wet[0] * b2a; a[0] += wet[1] * b2a; a[0] += wet[2] * b2a; a[0] += wet[3] * b2a;
             a[1] = 0.0F; a[1] += wet[0] * b2a; a[1] += wet[1] * -b2a; a[1] += wet[2] * -b2a; a[1] += wet[3] * b2a;
@@ -304,6 +337,11 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             a[3] = 0.0F; a[3] += wet[0] * b2a; a[3] += wet[1] * -b2a; a[3] += wet[2] * b2a; a[3] += wet[3] * -b2a;
 
             // ---------------- input shelves (reference src/oalsfxpp.cpp:7867-7879) ----------------
+            // group 0: a (lp input), group 1: feed-forward sums, group 2: lp output; then hp: 2 -> 1 -> 0
+            if (lane < 4) {
+                row(0, lane)[3] = lpx0; row(0, lane)[2] = lpx1;
+                row(2, lane)[3] = lpy0; row(2, lane)[2] = lpy1; // also the hp input history (hp.x == lp.y)
+            }
             if (act) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) row(0, c)[4 + lane] = a[c];
@@ -313,12 +351,15 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float* x = row(0, c) + 4 + lane;
-                    row(3, c)[4 + lane] = (P.lp.b0 * x[0]) + (P.lp.b1 * x[-1]) + (P.lp.b2 * x[-2]);
+                    row(1, c)[4 + lane] = (P.lp.b0 * x[0]) + (P.lp.b1 * x[-1]) + (P.lp.b2 * x[-2]);
                 }
             }
             wave_sync();
             if (lane < 4) {
-                biquad_chain(row(3, lane), row(1, lane), L, P.lp.a1, P.lp.a2);
+                const float* ra = row(0, lane);
+                const float nx1 = ra[4 + L - 2], nx0 = ra[4 + L - 1]; // L == 1: ra[3] is the old newest sample
+                lpx1 = nx1; lpx0 = nx0;
+                biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
             }
             wave_sync();
             float xin[4];
@@ -326,30 +367,27 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 if (act) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float* x = row(1, c) + 4 + lane;
-                        row(3, c)[4 + lane] = (P.hp.b0 * x[0]) + (P.hp.b1 * x[-1]) + (P.hp.b2 * x[-2]);
+                        const float* x = row(2, c) + 4 + lane;
+                        row(1, c)[4 + lane] = (P.hp.b0 * x[0]) + (P.hp.b1 * x[-1]) + (P.hp.b2 * x[-2]);
                     }
                 }
                 wave_sync();
-                if (lane < 4) biquad_chain(row(3, lane), row(2, lane), L, P.hp.a1, P.hp.a2);
+                if (lane < 4) {
+                    row(0, lane)[3] = hpy0; row(0, lane)[2] = hpy1;
+                    biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
+                }
                 wave_sync();
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xin[c] = row(2, c)[4 + lane];
+                for (int c = 0; c < 4; ++c) xin[c] = row(0, c)[4 + lane];
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xin[c] = row(1, c)[4 + lane];
-            }
-            wave_sync();
-            if (lane < 4) {
-                roll_history(row(0, lane), L);
-                roll_history(row(1, lane), L);
-                if (eax) roll_history(row(2, lane), L);
+                for (int c = 0; c < 4; ++c) xin[c] = row(2, c)[4 + lane];
             }
             if (act) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) ring[OALSFX_RV_MAIN].line(c)[t & ring[OALSFX_RV_MAIN].mask] = xin[c];
+                for (int c = 0; c < 4; ++c) r_main.line(c)[t & r_main.mask] = xin[c];
             }
-            mem_sync();
+            wave_sync();
 
             // ---------------- early reflections (reference src/oalsfxpp.cpp:7625-7672) ----------------
             float f[4] = {0.0F, 0.0F, 0.0F, 0.0F};
@@ -358,31 +396,36 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 if (act && lane >= sb && lane < sb + s) {
                     float g[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        f[j] = tap(ring[OALSFX_RV_MAIN], j, faded, t - cur_etap[j], t - new_etap[j], fade) * P.early_tap_coeff[j];
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = pre_e ? p_e[j] : tap(r_main, j, faded, t - cur_etap[j], t - P.early_tap[j], fade);
+                        f[j] = v * P.early_tap_coeff[j];
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float input = f[j];
-                        f[j] = tap(ring[OALSFX_RV_EARLY_AP], j, faded, t - cur_eap[j], t - new_eap[j], fade) - (apc * input);
+                        const float d = pre_a ? p_a[j] : tap(r_eap, j, faded, t - cur_eap[j], t - P.early_ap_off[j], fade);
+                        f[j] = d - (apc * input);
                         g[j] = input + (apc * f[j]);
                     }
                     scatter(g, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_EARLY_AP].line(j)[t & ring[OALSFX_RV_EARLY_AP].mask] = g[j];
+                    for (int j = 0; j < 4; ++j) r_eap.line(j)[t & r_eap.mask] = g[j];
                 }
                 sb += s;
-                if (sb < L) mem_sync();
+                wave_sync();
             }
             if (act) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ring[OALSFX_RV_EARLY_LINE].line(j)[t & ring[OALSFX_RV_EARLY_LINE].mask] = f[3 - j];
+                for (int j = 0; j < 4; ++j) r_eline.line(j)[t & r_eline.mask] = f[3 - j];
             }
-            mem_sync();
+            wave_sync();
             float early[4];
             if (act) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    f[j] += tap(ring[OALSFX_RV_EARLY_LINE], j, faded, t - cur_eline[j], t - new_eline[j], fade) * P.early_line_coeff[j];
+                for (int j = 0; j < 4; ++j) {
+                    const float d = pre_el ? p_el[j] : tap(r_eline, j, faded, t - cur_eline[j], t - P.early_line_off[j], fade);
+                    f[j] += d * P.early_line_coeff[j];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) early[j] = f[j];
@@ -391,10 +434,10 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 scatter(v, mx, my);
                 if (act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_MAIN].line(j)[(t - P.late_feed_tap) & ring[OALSFX_RV_MAIN].mask] = v[j];
+                    for (int j = 0; j < 4; ++j) r_main.line(j)[(t - P.late_feed_tap) & r_main.mask] = v[j];
                 }
             }
-            mem_sync();
+            wave_sync();
 
             // ---------------- late reverb (reference src/oalsfxpp.cpp:7735-7794) ----------------
             int md = 0;
@@ -403,6 +446,11 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 index %= mod_range;
                 const float sinus = glibc_sinf(6.28318530717958647692F * index / mod_range);
                 md = lround_away(rng[done + lane] * sinus);
+            }
+            // T60 history prefixes: group 0 = section-1 input, group 2 = section-1 output
+            if (lane < 4) {
+                row(0, lane)[3] = t60_x;
+                row(2, lane)[3] = t60_o1b;
             }
             float late[4] = {0.0F, 0.0F, 0.0F, 0.0F};
             for (int sb = 0; sb < L;) {
@@ -414,7 +462,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     const int d0 = cur_lline[j] + md;
                     ok &= (d0 > rel) || (d0 <= 0);
                     if (faded) {
-                        const int d1 = new_lline[j] + md;
+                        const int d1 = P.late_line_off[j] + md;
                         ok &= (d1 > rel) || (d1 <= 0);
                     }
                 }
@@ -426,51 +474,61 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     const int td = t - md;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float v = tap(ring[OALSFX_RV_MAIN], j, faded, t - cur_ltap[j], t - new_ltap[j], fade) * P.density_gain;
-                        v += tap(ring[OALSFX_RV_LATE_LINE], j, faded, td - cur_lline[j], td - new_lline[j], fade);
-                        row(3, j)[4 + lane] = v;
+                        const float m = pre_lt ? p_lt[j] : tap(r_main, j, faded, t - cur_ltap[j], t - P.late_tap[j], fade);
+                        float v = m * P.density_gain;
+                        v += pre_ll ? p_ll[j] : tap(r_lline, j, faded, td - cur_lline[j], td - P.late_line_off[j], fade);
+                        row(0, j)[4 + lane] = v;
                     }
                 }
                 wave_sync();
-                if (lane < 4) {
-                    // two first-order sections and the mid gain (reference src/oalsfxpp.cpp:7691-7719)
-                    float* u = row(3, lane) + 4;
-                    const float l0 = P.t60_lf[lane][0], l1 = P.t60_lf[lane][1], l2 = P.t60_lf[lane][2];
-                    const float h0 = P.t60_hf[lane][0], h1 = P.t60_hf[lane][1], h2 = P.t60_hf[lane][2];
-                    const float mid = P.t60_mid[lane];
-                    for (int i = sb; i < sb + s; ++i) {
-                        const float x = u[i];
-                        const float o1 = (l0 * x) + (l1 * t60_s00) + (l2 * t60_s01);
-                        t60_s00 = x;
-                        t60_s01 = o1;
-                        const float o2 = (h0 * o1) + (h1 * t60_s10) + (h2 * t60_s11);
-                        t60_s10 = o1;
-                        t60_s11 = o2;
-                        u[i] = mid * o2;
+                // T60: two first-order sections and the mid gain (reference src/oalsfxpp.cpp:7691-7719);
+                // feed-forward halves per lane, feedback halves on the chain lanes
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* x = row(0, j) + 4 + lane;
+                        row(1, j)[4 + lane] = (P.t60_lf[j][0] * x[0]) + (P.t60_lf[j][1] * x[-1]);
                     }
                 }
+                wave_sync();
+                if (lane < 4) first_order_chain(row(1, lane), row(2, lane), sb, sb + s, t_l2, 1.0F, false, t60_o1);
+                wave_sync();
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* o1 = row(2, j) + 4 + lane;
+                        row(1, j)[4 + lane] = (P.t60_hf[j][0] * o1[0]) + (P.t60_hf[j][1] * o1[-1]);
+                    }
+                }
+                wave_sync();
+                if (lane < 4) first_order_chain(row(1, lane), row(1, lane), sb, sb + s, t_h2, t_mid, true, t60_o2);
                 wave_sync();
                 if (on) {
                     float v[4], g[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float input = row(3, j)[4 + lane];
-                        v[j] = tap(ring[OALSFX_RV_LATE_AP], j, faded, t - cur_lap[j], t - new_lap[j], fade) - (apc * input);
+                        const float input = row(1, j)[4 + lane];
+                        const float d = pre_la ? p_la[j] : tap(r_lap, j, faded, t - cur_lap[j], t - P.late_ap_off[j], fade);
+                        v[j] = d - (apc * input);
                         g[j] = input + (apc * v[j]);
                     }
                     scatter(g, mx, my);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        ring[OALSFX_RV_LATE_AP].line(j)[t & ring[OALSFX_RV_LATE_AP].mask] = g[j];
+                        r_lap.line(j)[t & r_lap.mask] = g[j];
                         late[j] = v[j];
                     }
                     float r[4] = {v[3], v[2], v[1], v[0]};
                     scatter(r, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ring[OALSFX_RV_LATE_LINE].line(j)[t & ring[OALSFX_RV_LATE_LINE].mask] = r[j];
+                    for (int j = 0; j < 4; ++j) r_lline.line(j)[t & r_lline.mask] = r[j];
                 }
                 sb += s;
-                if (sb < L) mem_sync();
+                wave_sync();
+            }
+            if (lane < 4) {
+                t60_x = row(0, lane)[4 + L - 1];
+                t60_o1b = t60_o1; // the second section's last input is the first section's last output
             }
 
             // ---------------- pan to the outputs with gain ramps (reference src/oalsfxpp.cpp:6142-6166) ----------------
@@ -531,8 +589,8 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 fade_count = OALSFX_RV_FADE_SAMPLES;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    cur_etap[j] = new_etap[j]; cur_eap[j] = new_eap[j]; cur_eline[j] = new_eline[j];
-                    cur_ltap[j] = new_ltap[j]; cur_lap[j] = new_lap[j]; cur_lline[j] = new_lline[j];
+                    cur_etap[j] = P.early_tap[j]; cur_eap[j] = P.early_ap_off[j]; cur_eline[j] = P.early_line_off[j];
+                    cur_ltap[j] = P.late_tap[j]; cur_lap[j] = P.late_ap_off[j]; cur_lline[j] = P.late_line_off[j];
                 }
             }
         }
@@ -542,17 +600,15 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     }
 
     // ---- write the state back ----
-    wave_sync();
     if (lane < 4) {
-        const float* r0 = row(0, lane); const float* r1 = row(1, lane); const float* r2 = row(2, lane);
-        S.lp[lane].x[0] = r0[3]; S.lp[lane].x[1] = r0[2];
-        S.lp[lane].y[0] = r1[3]; S.lp[lane].y[1] = r1[2];
+        S.lp[lane].x[0] = lpx0; S.lp[lane].x[1] = lpx1;
+        S.lp[lane].y[0] = lpy0; S.lp[lane].y[1] = lpy1;
         if (eax) {
-            S.hp[lane].x[0] = r1[3]; S.hp[lane].x[1] = r1[2];
-            S.hp[lane].y[0] = r2[3]; S.hp[lane].y[1] = r2[2];
+            S.hp[lane].x[0] = lpy0; S.hp[lane].x[1] = lpy1; // the hp input is the lp output
+            S.hp[lane].y[0] = hpy0; S.hp[lane].y[1] = hpy1;
         }
-        S.t60[lane][0][0] = t60_s00; S.t60[lane][0][1] = t60_s01;
-        S.t60[lane][1][0] = t60_s10; S.t60[lane][1][1] = t60_s11;
+        S.t60[lane][0][0] = t60_x; S.t60[lane][0][1] = t60_o1;
+        S.t60[lane][1][0] = t60_o1b; S.t60[lane][1][1] = t60_o2;
     }
     if (q_valid) {
         if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
