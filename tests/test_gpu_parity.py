@@ -134,3 +134,25 @@ def test_mixed_slots_with_nulls_and_type_changes():
 def test_other_channel_formats(fmt):
     setups = [[(0, E(t))] for t in (desc.EAX_REVERB, desc.CHORUS, desc.ECHO, desc.EQUALIZER, desc.DEDICATED_DIALOG, desc.COMPRESSOR)]
     run_batch(fmt, 44100, 1, setups, [("mix", 200)] * 3)
+
+
+def test_cpp_api_dropin(tmp_path):
+    """A C++ caller of the reference's public API, compiled against include/oalsfxpp.h and linked to the HIP library."""
+    import os
+    import subprocess
+    from harness import OracleApi, ROOT
+    from oalsfxpp_amd import lib
+    exe, out = str(tmp_path / "dropin"), str(tmp_path / "out.f32")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "api_dropin.cpp"),
+                    "-L", libdir, "-loalsfx_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    r = subprocess.run([exe, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(out, dtype=np.float32)
+    api = OracleApi(desc.FMT_STEREO, 48000, 2)
+    api.set_effect(0, preset_effect(112))
+    api.set_effect_type(1, desc.CHORUS)
+    api.apply_changes()
+    want = np.concatenate([api.mix(orc.synth(77, k, n * 2).reshape(n, 2)).reshape(-1) for k, n in enumerate((256, 256, 256, 100, 3000))])
+    ok, nbad = same_bits(got, want)
+    assert ok, f"{nbad} of {want.size} samples differ"
