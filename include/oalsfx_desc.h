@@ -229,6 +229,23 @@ typedef struct {
     float late_cur_gain[4][OALSFX_MAX_CHANNELS];
 } oalsfx_reverb_state;
 
+/* Placement of the five reverb rings inside an instance's slab: longest ring first (stable), four
+ * lines each.  All lengths are powers of two, so every line then starts at a multiple of its own
+ * length and a kernel can form "line base | (position & (len-1))" with one AND-OR. */
+static inline void oalsfx_reverb_place_rings(const int32_t len[5], int32_t off[5])
+{
+    int32_t order[5] = {0, 1, 2, 3, 4};
+    int32_t at = 0;
+    for (int i = 1; i < 5; ++i)
+        for (int k = i; k > 0 && len[order[k]] > len[order[k - 1]]; --k) {
+            const int32_t t = order[k]; order[k] = order[k - 1]; order[k - 1] = t;
+        }
+    for (int i = 0; i < 5; ++i) {
+        off[order[i]] = at;
+        at += 4 * len[order[i]];
+    }
+}
+
 /* ---------------------------------------------------------------------------
  * One effect slot of one instance
  * ------------------------------------------------------------------------- */

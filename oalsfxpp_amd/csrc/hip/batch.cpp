@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -291,7 +292,10 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
         tl.type = type;
         hipEventRecord(tl.start, stream);
     }
-    if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) oalsfx_hip::launch_reverb(ctx, slot, list, count, flags, stream);
+    if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) {
+        static const int debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
+        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (debug_flags << 8), stream);
+    }
     else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
     if (b->timing) {
         hipEventRecord(tl.stop, stream);

@@ -57,20 +57,24 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ int min_positive(int limit, int d) { return (d > 0 && d < limit) ? d : limit; }
 __device__ __forceinline__ int min4(const int v[4]) { return min(min(v[0], v[1]), min(v[2], v[3])); }
 
+// A ring in byte terms: line j of the ring starts `lo[j]` bytes into the slab and is `bmask + 4` bytes long.
+// Rings are placed longest-first (oalsfx_reverb_place_rings), so every line starts at a multiple of its
+// own length and "line base | wrapped position" is one AND-OR on a 32-bit byte offset.
 struct Ring {
-    float* base; // line 0
-    int len;
-    int mask;
-    __device__ __forceinline__ float* line(int j) const { return base + j * len; }
+    unsigned lo[4];
+    unsigned bmask;
+    __device__ __forceinline__ unsigned at(int j, unsigned pos4) const { return (pos4 & bmask) | lo[j]; }
 };
 
-// delay_out_faded / delay_out_unfaded (reference src/oalsfxpp.cpp:7358-7399)
-__device__ __forceinline__ float tap(const Ring& r, int j, bool faded, int pos0, int pos1, float mu)
+__device__ __forceinline__ float ld(const char* slab, unsigned byte_off) { return *reinterpret_cast<const float*>(slab + byte_off); }
+__device__ __forceinline__ void st(char* slab, unsigned byte_off, float v) { *reinterpret_cast<float*>(slab + byte_off) = v; }
+
+// delay_out_faded / delay_out_unfaded (reference src/oalsfxpp.cpp:7358-7399); pos4 = 4 * sample position
+__device__ __forceinline__ float tap(const char* slab, const Ring& r, int j, bool faded, unsigned pos4_0, unsigned pos4_1, float mu)
 {
-    const float* l = r.line(j);
-    const float a = l[pos0 & r.mask];
+    const float a = ld(slab, r.at(j, pos4_0));
     if (!faded) return a;
-    const float b = l[pos1 & r.mask];
+    const float b = ld(slab, r.at(j, pos4_1));
     return lerpf(a, b, mu);
 }
 
@@ -154,22 +158,27 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
-    const oalsfx_slot_params& SP = ctx.params[sidx];
-    const oalsfx_reverb_params& P = SP.u.reverb;
+    // parameters are read-only for the whole launch: address space 4 (constant) makes every access a scalar load
+    typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
+    typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
+    ConstSlotParams& SP = *(ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
+    const auto& P = SP.u.reverb;
     oalsfx_slot_state& SS = ctx.state[sidx];
     oalsfx_reverb_state& S = SS.u.reverb;
-    const oalsfx_source_params& SRC = ctx.source[inst];
+    ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
     float* slab = ctx.rings[sidx];
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
     const bool eax = P.is_eax != 0;
+    const int dbg = flags >> 8; // timing experiments only (OALSFX_DEBUG_FLAGS): 1 skip chains, 2 skip ring loads, 4 skip ring stores
 
+    char* slab_b = reinterpret_cast<char*>(slab);
     Ring ring[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        ring[r].base = slab + P.ring_off[r];
-        ring[r].len = P.ring_len[r];
-        ring[r].mask = P.ring_len[r] - 1;
+        ring[r].bmask = static_cast<unsigned>(P.ring_len[r] - 1) << 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring[r].lo[j] = static_cast<unsigned>(P.ring_off[r] + j * P.ring_len[r]) << 2;
     }
     const Ring& r_main = ring[OALSFX_RV_MAIN];
     const Ring& r_eap = ring[OALSFX_RV_EARLY_AP];
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             const int L = min(64, todo - done);
             const bool act = lane < L;
             const int t = offset + done + lane;                 // absolute sample index of this lane
+            const unsigned t4 = static_cast<unsigned>(t) << 2;    // ... as a byte position in a float ring
             const int pos = base + done + lane;                 // index inside the caller's chunk
             const float fade = static_cast<float>(fade_count + done + lane) * (1.0F / OALSFX_RV_FADE_SAMPLES);
 
@@ -297,13 +307,13 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 p_e[j] = p_a[j] = p_el[j] = p_lt[j] = p_ll[j] = p_la[j] = 0.0F;
-                if (act) {
-                    if (pre_e) p_e[j] = r_main.line(j)[(t - cur_etap[j]) & r_main.mask];
-                    if (pre_a) p_a[j] = r_eap.line(j)[(t - cur_eap[j]) & r_eap.mask];
-                    if (pre_el) p_el[j] = r_eline.line(j)[(t - cur_eline[j]) & r_eline.mask];
-                    if (pre_lt) p_lt[j] = r_main.line(j)[(t - cur_ltap[j]) & r_main.mask];
-                    if (pre_ll) p_ll[j] = r_lline.line(j)[(t - cur_lline[j]) & r_lline.mask];
-                    if (pre_la) p_la[j] = r_lap.line(j)[(t - cur_lap[j]) & r_lap.mask];
+                if (act && !(dbg & 2)) {
+                    if (pre_e) p_e[j] = ld(slab_b, r_main.at(j, t4 - 4u * cur_etap[j]));
+                    if (pre_a) p_a[j] = ld(slab_b, r_eap.at(j, t4 - 4u * cur_eap[j]));
+                    if (pre_el) p_el[j] = ld(slab_b, r_eline.at(j, t4 - 4u * cur_eline[j]));
+                    if (pre_lt) p_lt[j] = ld(slab_b, r_main.at(j, t4 - 4u * cur_ltap[j]));
+                    if (pre_ll) p_ll[j] = ld(slab_b, r_lline.at(j, t4 - 4u * cur_lline[j]));
+                    if (pre_la) p_la[j] = ld(slab_b, r_lap.at(j, t4 - 4u * cur_lap[j]));
                 }
             }
             if (!first && act) {
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 const float* ra = row(0, lane);
                 const float nx1 = ra[4 + L - 2], nx0 = ra[4 + L - 1]; // L == 1: ra[3] is the old newest sample
                 lpx1 = nx1; lpx0 = nx0;
-                biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
+                if (!(dbg & 1)) biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
             }
             wave_sync();
             float xin[4];
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 wave_sync();
                 if (lane < 4) {
                     row(0, lane)[3] = hpy0; row(0, lane)[2] = hpy1;
-                    biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
+                    if (!(dbg & 1)) biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
                 }
                 wave_sync();
 #pragma unroll
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             }
             if (act) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) r_main.line(c)[t & r_main.mask] = xin[c];
+                for (int c = 0; c < 4; ++c) if (!(dbg & 4)) st(slab_b, r_main.at(c, t4), xin[c]);
             }
             wave_sync();
 
@@ -397,33 +407,33 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     float g[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = pre_e ? p_e[j] : tap(r_main, j, faded, t - cur_etap[j], t - P.early_tap[j], fade);
+                        const float v = pre_e ? p_e[j] : tap(slab_b, r_main, j, faded, t4 - 4u * cur_etap[j], t4 - 4u * P.early_tap[j], fade);
                         f[j] = v * P.early_tap_coeff[j];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float input = f[j];
-                        const float d = pre_a ? p_a[j] : tap(r_eap, j, faded, t - cur_eap[j], t - P.early_ap_off[j], fade);
+                        const float d = pre_a ? p_a[j] : tap(slab_b, r_eap, j, faded, t4 - 4u * cur_eap[j], t4 - 4u * P.early_ap_off[j], fade);
                         f[j] = d - (apc * input);
                         g[j] = input + (apc * f[j]);
                     }
                     scatter(g, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) r_eap.line(j)[t & r_eap.mask] = g[j];
+                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_eap.at(j, t4), g[j]);
                 }
                 sb += s;
                 wave_sync();
             }
             if (act) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r_eline.line(j)[t & r_eline.mask] = f[3 - j];
+                for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_eline.at(j, t4), f[3 - j]);
             }
             wave_sync();
             float early[4];
             if (act) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d = pre_el ? p_el[j] : tap(r_eline, j, faded, t - cur_eline[j], t - P.early_line_off[j], fade);
+                    const float d = pre_el ? p_el[j] : tap(slab_b, r_eline, j, faded, t4 - 4u * cur_eline[j], t4 - 4u * P.early_line_off[j], fade);
                     f[j] += d * P.early_line_coeff[j];
                 }
             }
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 scatter(v, mx, my);
                 if (act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) r_main.line(j)[(t - P.late_feed_tap) & r_main.mask] = v[j];
+                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_main.at(j, t4 - 4u * P.late_feed_tap), v[j]);
                 }
             }
             wave_sync();
@@ -471,12 +481,12 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                 const int s = min(min(L - sb, lap_limit), lead);
                 const bool on = act && lane >= sb && lane < sb + s;
                 if (on) {
-                    const int td = t - md;
+                    const unsigned td4 = t4 - 4u * static_cast<unsigned>(md);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float m = pre_lt ? p_lt[j] : tap(r_main, j, faded, t - cur_ltap[j], t - P.late_tap[j], fade);
+                        const float m = pre_lt ? p_lt[j] : tap(slab_b, r_main, j, faded, t4 - 4u * cur_ltap[j], t4 - 4u * P.late_tap[j], fade);
                         float v = m * P.density_gain;
-                        v += pre_ll ? p_ll[j] : tap(r_lline, j, faded, td - cur_lline[j], td - P.late_line_off[j], fade);
+                        v += pre_ll ? p_ll[j] : tap(slab_b, r_lline, j, faded, td4 - 4u * cur_lline[j], td4 - 4u * P.late_line_off[j], fade);
                         row(0, j)[4 + lane] = v;
                     }
                 }
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     }
                 }
                 wave_sync();
-                if (lane < 4) first_order_chain(row(1, lane), row(2, lane), sb, sb + s, t_l2, 1.0F, false, t60_o1);
+                if (lane < 4 && !(dbg & 1)) first_order_chain(row(1, lane), row(2, lane), sb, sb + s, t_l2, 1.0F, false, t60_o1);
                 wave_sync();
                 if (on) {
 #pragma unroll
@@ -501,27 +511,27 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
                     }
                 }
                 wave_sync();
-                if (lane < 4) first_order_chain(row(1, lane), row(1, lane), sb, sb + s, t_h2, t_mid, true, t60_o2);
+                if (lane < 4 && !(dbg & 1)) first_order_chain(row(1, lane), row(1, lane), sb, sb + s, t_h2, t_mid, true, t60_o2);
                 wave_sync();
                 if (on) {
                     float v[4], g[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float input = row(1, j)[4 + lane];
-                        const float d = pre_la ? p_la[j] : tap(r_lap, j, faded, t - cur_lap[j], t - P.late_ap_off[j], fade);
+                        const float d = pre_la ? p_la[j] : tap(slab_b, r_lap, j, faded, t4 - 4u * cur_lap[j], t4 - 4u * P.late_ap_off[j], fade);
                         v[j] = d - (apc * input);
                         g[j] = input + (apc * v[j]);
                     }
                     scatter(g, mx, my);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        r_lap.line(j)[t & r_lap.mask] = g[j];
+                        if (!(dbg & 4)) st(slab_b, r_lap.at(j, t4), g[j]);
                         late[j] = v[j];
                     }
                     float r[4] = {v[3], v[2], v[1], v[0]};
                     scatter(r, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) r_lline.line(j)[t & r_lline.mask] = r[j];
+                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_lline.at(j, t4), r[j]);
                 }
                 sb += s;
                 wave_sync();

@@ -415,11 +415,7 @@ void derive_reverb(const DeviceDesc& dev, bool is_eax, const EffectProps::Reverb
 
     // ---- rate-only quantities (reference do_update_device, src/oalsfxpp.cpp:5928-5950) ----
     ring_lengths(frequency, o.ring_len);
-    int off = 0;
-    for (int r = 0; r < 5; ++r) {
-        o.ring_off[r] = off;
-        off += 4 * o.ring_len[r];
-    }
+    oalsfx_reverb_place_rings(o.ring_len, o.ring_off);
     o.mod_coeff = std::pow(modulation_filter_coeff, modulation_filter_const / frequency);
     const float max_multiplier = 1.0F + line_multiplier;
     o.late_feed_tap = static_cast<int>((R::max_reflections_delay + (early_tap_lengths[3] * max_multiplier)) * frequency);

@@ -192,7 +192,7 @@ void ref_dump_source(void* h, oalsfx_source_params* p, oalsfx_source_state* s)
 }
 
 // Dumps slot `idx`.  Ring layout fields (ring_len / ring_off) are filled with the
-// repository's convention: rings packed in order, 4 contiguous lines each.
+// repository's convention (oalsfx_reverb_place_rings): longest ring first, 4 contiguous lines each.
 int ref_dump_slot(void* h, int idx, oalsfx_slot_params* p, oalsfx_slot_state* s)
 {
     auto& impl = *static_cast<Api*>(h)->pimpl_;
@@ -305,12 +305,8 @@ int ref_dump_slot(void* h, int idx, oalsfx_slot_params* p, oalsfx_slot_state* s)
         }
         const ReverbEffectState::DelayLineI* rings[5] = {
             &e.delay_, &e.early_.vec_ap_.delay_, &e.early_.delay_, &e.late_.vec_ap_.delay_, &e.late_.delay_};
-        int off = 0;
-        for (int r = 0; r < 5; ++r) {
-            o.ring_len[r] = rings[r]->get_sample_count();
-            o.ring_off[r] = off;
-            off += 4 * o.ring_len[r];
-        }
+        for (int r = 0; r < 5; ++r) o.ring_len[r] = rings[r]->get_sample_count();
+        oalsfx_reverb_place_rings(o.ring_len, o.ring_off);
         q.mod_index = e.mod_.index_; q.mod_range = e.mod_.range_; q.mod_filter = e.mod_.filter_;
         q.fade_count = e.fade_count_; q.offset = e.offset_;
         break;
