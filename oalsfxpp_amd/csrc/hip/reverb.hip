@@ -39,11 +39,46 @@ constexpr int kRow = 68;          // 4 (history prefix, 16-byte aligned data) + 
 constexpr int kGroups = 3;        // row groups, 4 lines each
 constexpr int kRngFloats = OALSFX_RV_MAX_UPDATE;
 
+// Per-wave table of instance constants kept in LDS (dword offsets).  The steady-state tile reads them
+// with broadcast ds_reads right where they are used: they cost no VALU slot and no long-lived SGPRs.
+namespace ut {
+enum {
+    TAP4 = 0,    // 6 groups x 4 lines: current taps as byte distances (early tap, early AP, early line, late tap, late AP, late line)
+    LO = 24,     // 5 rings x 4 lines: byte offset of each line in the slab
+    BMASK = 44,  // 5 rings: (len - 1) * 4
+    FEED4 = 49,  // late_feed_tap * 4
+    ECOEF = 52, ELCOEF = 56,
+    MISC = 60,   // density_gain, ap_feed_coeff, mix_x, mix_y
+    LPB = 64, HPB = 68,        // b0, b1, b2 of the input shelves
+    TL0 = 72, TL1 = 76, TH0 = 80, TH1 = 84, // T60 feed-forward coefficients per line
+    GOUT = 88,   // 16 output gains of the chunk, chain order q = (stage*4 + line)*2 + channel (stereo / mono only)
+    GDIR = 104,  // direct gains [in][out] (2x2)
+    GAUX = 108,  // aux gains [in][k] (2x4)
+    SIZE = 116
+};
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
 template <int CH>
 struct Lds {
     static constexpr int kChains = 8 * CH; // (early|late) x 4 lines x channels gain ramps
-    static constexpr int kFloats = kGroups * 4 * kRow + kRngFloats + kChains * 64;
+    static constexpr int kFloats = kGroups * 4 * kRow + kRngFloats + kChains * 64 + ut::SIZE;
 };
+
+// packed form of vector_partial_scatter on (v0,v1 | v2,v3); same association as the scalar form
+__device__ __forceinline__ void scatter2(v2f& a, v2f& b, float x, float y)
+{
+    const float v0 = a.x, v1 = a.y, v2 = b.x, v3 = b.y;
+    v2f s0 = v2f{v1, -v0} + v2f{-v2, v2};
+    s0 = s0 + v2f{v3, v3};
+    v2f s1 = v2f{v0, -v0} + v2f{-v1, -v1};
+    s1 = s1 + v2f{v3, -v2};
+    a = (x * a) + (y * s0);
+    b = (x * b) + (y * s1);
+}
 
 // Hand-off between lanes of one wavefront through LDS or through the rings in global memory:
 // pins the compiler; the hardware keeps one wavefront's memory operations in program order.
@@ -153,6 +188,8 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
     float* rng = lds + kGroups * 4 * kRow;
     float* gseq = rng + kRngFloats;
+    float* utf = gseq + NQ * 64;                             // uniform table, float view
+    unsigned* utu = reinterpret_cast<unsigned*>(utf);        // ... unsigned view
 
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     const int channels = (CH == 8) ? ctx.channels : CH;
@@ -189,12 +226,6 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     // ---- instance state into registers (all wave-uniform) ----
     int fade_count = S.fade_count, offset = S.offset, mod_index = S.mod_index, mod_range = S.mod_range;
     float mod_filter = S.mod_filter;
-    int cur_etap[4], cur_eap[4], cur_eline[4], cur_ltap[4], cur_lap[4], cur_lline[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cur_etap[j] = S.cur_early_tap[j]; cur_eap[j] = S.cur_early_ap_off[j]; cur_eline[j] = S.cur_early_line_off[j];
-        cur_ltap[j] = S.cur_late_tap[j]; cur_lap[j] = S.cur_late_ap_off[j]; cur_lline[j] = S.cur_late_line_off[j];
-    }
 
     // pending parameter update: what do_update does to state (reference src/oalsfxpp.cpp:7028-7031, 6062-6075)
     if (SS.seen_seq != SP.update_seq) {
@@ -203,10 +234,52 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
         bool differ = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            differ |= (P.early_tap[j] != cur_etap[j]) | (P.early_ap_off[j] != cur_eap[j]) | (P.early_line_off[j] != cur_eline[j]) |
-                      (P.late_tap[j] != cur_ltap[j]) | (P.late_ap_off[j] != cur_lap[j]) | (P.late_line_off[j] != cur_lline[j]);
+            differ |= (P.early_tap[j] != S.cur_early_tap[j]) | (P.early_ap_off[j] != S.cur_early_ap_off[j]) |
+                      (P.early_line_off[j] != S.cur_early_line_off[j]) | (P.late_tap[j] != S.cur_late_tap[j]) |
+                      (P.late_ap_off[j] != S.cur_late_ap_off[j]) | (P.late_line_off[j] != S.cur_late_line_off[j]);
         if (differ) fade_count = 0;
     }
+
+    // ---- per-wave table of instance constants in LDS (see namespace ut) ----
+    // the six current-tap arrays are contiguous in oalsfx_reverb_state, in the table's group order
+    if (lane < 24) utu[ut::TAP4 + lane] = 4u * static_cast<unsigned>((&S.cur_early_tap[0])[lane]);
+    if (lane < 20) {
+        const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb;
+        const int r = lane >> 2, j = lane & 3;
+        utu[ut::LO + lane] = static_cast<unsigned>(PG.ring_off[r] + j * PG.ring_len[r]) << 2;
+        if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(PG.ring_len[lane] - 1) << 2;
+        if (lane < 4) {
+            utf[ut::ECOEF + lane] = PG.early_tap_coeff[lane];
+            utf[ut::ELCOEF + lane] = PG.early_line_coeff[lane];
+            utf[ut::TL0 + lane] = PG.t60_lf[lane][0];
+            utf[ut::TL1 + lane] = PG.t60_lf[lane][1];
+            utf[ut::TH0 + lane] = PG.t60_hf[lane][0];
+            utf[ut::TH1 + lane] = PG.t60_hf[lane][1];
+        }
+        if (CH <= 2) {
+            const oalsfx_source_params& SG = ctx.source[inst];
+            if (lane < 4) utf[ut::GDIR + lane] = SG.direct.gains[lane >> 1][lane & 1];
+            if (lane < 8) utf[ut::GAUX + lane] = SG.aux[slot].gains[lane >> 2][lane & 3];
+        }
+    }
+    if (lane == 0) {
+        utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
+        utf[ut::MISC + 0] = P.density_gain; utf[ut::MISC + 1] = P.ap_feed_coeff; utf[ut::MISC + 2] = P.mix_x; utf[ut::MISC + 3] = P.mix_y;
+        utf[ut::LPB + 0] = P.lp.b0; utf[ut::LPB + 1] = P.lp.b1; utf[ut::LPB + 2] = P.lp.b2; utf[ut::LPB + 3] = 0.0F;
+        utf[ut::HPB + 0] = P.hp.b0; utf[ut::HPB + 1] = P.hp.b1; utf[ut::HPB + 2] = P.hp.b2; utf[ut::HPB + 3] = 0.0F;
+    }
+    // audible send gains as bit masks (stereo / mono): bit c*2+o for the dry mix, bit c*4+k for the B-format send
+    unsigned aud_dir = 0, aud_aux = 0;
+    if (CH <= 2) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int o = 0; o < CH; ++o) aud_dir |= audible(SRC.direct.gains[c][o]) ? 1u << (c * 2 + o) : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aud_aux |= audible(SRC.aux[slot].gains[c][k]) ? 1u << (c * 4 + k) : 0u;
+        }
+    }
+    wave_sync();
 
     // ---- chain lanes (0..3, one per line): filter histories in registers ----
     const int cl = lane & 3;
@@ -258,6 +331,17 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             wave_sync();
         }
 
+        // current taps of this chunk (wave-uniform; they only change when a cross-fade completes)
+        int cur_etap[4], cur_eap[4], cur_eline[4], cur_ltap[4], cur_lap[4], cur_lline[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cur_etap[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 0 + j] >> 2);
+            cur_eap[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 4 + j] >> 2);
+            cur_eline[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 8 + j] >> 2);
+            cur_ltap[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 12 + j] >> 2);
+            cur_lap[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 16 + j] >> 2);
+            cur_lline[j] = __builtin_amdgcn_readfirstlane(utu[ut::TAP4 + 20 + j] >> 2);
+        }
         // early / late feedback limits: the shortest positive all-pass delay in use
         int eap_limit = 64, lap_limit = 64;
 #pragma unroll
@@ -277,6 +361,16 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
         const bool pre_lt = pre && min4(cur_ltap) >= P.late_feed_tap + 64;
         const bool pre_la = pre && min4(cur_lap) >= 64;
         const bool pre_ll = pre_la && !mod_active && min4(cur_lline) >= 64;
+        // the steady-state tile: no cross-fade, no modulation, no gain ramp, every tap outside the tile
+        const bool fast = (CH <= 2) && pre_e && pre_a && pre_el && pre_lt && pre_ll && (ramp_mask == 0ULL);
+        unsigned aud_out = 0;
+        if (fast) {
+            aud_out = static_cast<unsigned>(__ballot(q_valid && audible(g_cur)));
+            if (q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
+            if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
+                                    ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
+            wave_sync();
+        }
 
         for (int done = 0; done < todo; done += 64) {
             const int L = min(64, todo - done);
@@ -285,6 +379,217 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             const unsigned t4 = static_cast<unsigned>(t) << 2;    // ... as a byte position in a float ring
             const int pos = base + done + lane;                 // index inside the caller's chunk
             const float fade = static_cast<float>(fade_count + done + lane) * (1.0F / OALSFX_RV_FADE_SAMPLES);
+
+            if (fast) {
+                // ================= steady-state tile: packed arithmetic, constants from the LDS table =================
+                wave_sync(); // ring stores of the previous tile precede the loads below (program order)
+                const v4u lo_main = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * OALSFX_RV_MAIN);
+                const v4u lo_eap = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * OALSFX_RV_EARLY_AP);
+                const v4u lo_eline = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * OALSFX_RV_EARLY_LINE);
+                const v4u lo_lap = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * OALSFX_RV_LATE_AP);
+                const v4u lo_lline = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * OALSFX_RV_LATE_LINE);
+                const unsigned bm_main = utu[ut::BMASK + OALSFX_RV_MAIN], bm_eap = utu[ut::BMASK + OALSFX_RV_EARLY_AP],
+                               bm_eline = utu[ut::BMASK + OALSFX_RV_EARLY_LINE], bm_lap = utu[ut::BMASK + OALSFX_RV_LATE_AP],
+                               bm_lline = utu[ut::BMASK + OALSFX_RV_LATE_LINE];
+                auto load4 = [&](int group, unsigned bm, const v4u& lo) -> v4f {
+                    const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+                    v4f r = {0.0F, 0.0F, 0.0F, 0.0F};
+                    if (!(dbg & 2)) {
+                        r.x = ld(slab_b, ((t4 - d.x) & bm) | lo.x);
+                        r.y = ld(slab_b, ((t4 - d.y) & bm) | lo.y);
+                        r.z = ld(slab_b, ((t4 - d.z) & bm) | lo.z);
+                        r.w = ld(slab_b, ((t4 - d.w) & bm) | lo.w);
+                    }
+                    return r;
+                };
+                auto store4 = [&](unsigned p4, unsigned bm, const v4u& lo, float v0, float v1, float v2, float v3) {
+                    if (act && !(dbg & 4)) {
+                        const unsigned wp = p4 & bm;
+                        st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
+                    }
+                };
+                // ---- loads: nothing of this tile is needed to issue them ----
+                float in0 = 0.0F, in1 = 0.0F;
+                if (act) {
+                    if (CH == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(pos) * 2);
+                        in0 = v.x; in1 = v.y;
+                    } else {
+                        in0 = src[pos];
+                    }
+                }
+                const v4f p_e = load4(0, bm_main, lo_main);
+                const v4f p_a = load4(1, bm_eap, lo_eap);
+                const v4f p_el = load4(2, bm_eline, lo_eline);
+                const v4f p_lt = load4(3, bm_main, lo_main);
+                const v4f p_la = load4(4, bm_lap, lo_lap);
+                const v4f p_ll = load4(5, bm_lline, lo_lline);
+                float o0 = 0.0F, o1 = 0.0F;
+                if (!first && act) {
+                    o0 = mixbuf[pos];
+                    if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
+                }
+                // ---- input: dry mix, B-format send, A-format ----
+                const float in[2] = {in0, in1};
+                if (first) {
+                    const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
+                    const float g[4] = {gd.x, gd.y, gd.z, gd.w};
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (aud_dir & (1u << (c * 2 + 0))) o0 += in[c] * g[c * 2 + 0];
+                        if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) o1 += in[c] * g[c * 2 + 1];
+                    }
+                }
+                float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
+                    const float g[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (aud_aux & (1u << (c * 4 + k))) wet[k] += in[c] * g[k];
+                }
+                v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
+                a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
+                a23 = a23 + wet[0] * v2f{b2a, b2a}; a23 = a23 + wet[1] * v2f{b2a, -b2a}; a23 = a23 + wet[2] * v2f{-b2a, b2a}; a23 = a23 + wet[3] * v2f{-b2a, -b2a};
+
+                // ---- input shelves: group 0 = a, 1 = feed-forward sums, 2 = lp output; then hp: 2 -> 1 -> 0 ----
+                if (lane < 4) {
+                    row(0, lane)[3] = lpx0; row(0, lane)[2] = lpx1;
+                    row(2, lane)[3] = lpy0; row(2, lane)[2] = lpy1;
+                }
+                row(0, 0)[4 + lane] = a01.x; row(0, 1)[4 + lane] = a01.y; row(0, 2)[4 + lane] = a23.x; row(0, 3)[4 + lane] = a23.y;
+                wave_sync();
+                {
+                    const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::LPB);
+                    const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
+                    const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
+                    const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                    const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                    row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
+                }
+                wave_sync();
+                if (lane < 4) {
+                    const float* ra = row(0, lane);
+                    const float nx1 = ra[4 + L - 2], nx0 = ra[4 + L - 1];
+                    lpx1 = nx1; lpx0 = nx0;
+                    if (!(dbg & 1)) biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
+                }
+                wave_sync();
+                int xg = 2;
+                if (eax) {
+                    const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
+                    const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
+                    const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
+                    const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                    const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                    row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
+                    wave_sync();
+                    if (lane < 4 && !(dbg & 1)) biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
+                    wave_sync();
+                    xg = 0;
+                }
+                store4(t4, bm_main, lo_main, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
+                wave_sync();
+
+                // ---- early reflections ----
+                const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC); // density gain, all-pass coefficient, mix x, mix y
+                const float dg = misc.x, ac = misc.y, sx = misc.z, sy = misc.w;
+                const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
+                const v4f elc = *reinterpret_cast<const v4f*>(utf + ut::ELCOEF);
+                v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
+                v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
+                v2f v01 = v2f{p_a.x, p_a.y} - (ac * f01);
+                v2f v23 = v2f{p_a.z, p_a.w} - (ac * f23);
+                v2f g01 = f01 + (ac * v01);
+                v2f g23 = f23 + (ac * v23);
+                scatter2(g01, g23, sx, sy);
+                store4(t4, bm_eap, lo_eap, g01.x, g01.y, g23.x, g23.y);
+                store4(t4, bm_eline, lo_eline, v23.y, v23.x, v01.y, v01.x); // the early line is fed in reverse line order
+                const v2f e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
+                const v2f e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
+                {
+                    v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
+                    scatter2(r01, r23, sx, sy);
+                    store4(t4 - utu[ut::FEED4], bm_main, lo_main, r01.x, r01.y, r23.x, r23.y);
+                }
+
+                // ---- late reverb: taps, T60 (feed-forward per lane, feedback on the chain lanes), all-pass ----
+                {
+                    const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
+                    const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
+                    if (lane < 4) {
+                        row(0, lane)[3] = t60_x;
+                        row(2, lane)[3] = t60_o1b;
+                    }
+                    row(0, 0)[4 + lane] = u01.x; row(0, 1)[4 + lane] = u01.y; row(0, 2)[4 + lane] = u23.x; row(0, 3)[4 + lane] = u23.y;
+                }
+                wave_sync();
+                {
+                    const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TL0);
+                    const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TL1);
+                    const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
+                    const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
+                    const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
+                    const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
+                    row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+                }
+                wave_sync();
+                if (lane < 4 && !(dbg & 1)) first_order_chain(row(1, lane), row(2, lane), 0, L, t_l2, 1.0F, false, t60_o1);
+                wave_sync();
+                {
+                    const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
+                    const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TH1);
+                    const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
+                    const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
+                    const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
+                    const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
+                    row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+                }
+                wave_sync();
+                if (lane < 4) {
+                    if (!(dbg & 1)) first_order_chain(row(1, lane), row(1, lane), 0, L, t_h2, t_mid, true, t60_o2);
+                    t60_x = row(0, lane)[4 + L - 1];
+                    t60_o1b = t60_o1;
+                }
+                wave_sync();
+                v2f l01, l23;
+                {
+                    const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
+                    const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
+                    l01 = v2f{p_la.x, p_la.y} - (ac * i01);
+                    l23 = v2f{p_la.z, p_la.w} - (ac * i23);
+                    v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
+                    scatter2(q01, q23, sx, sy);
+                    store4(t4, bm_lap, lo_lap, q01.x, q01.y, q23.x, q23.y);
+                    v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
+                    scatter2(r01, r23, sx, sy);
+                    store4(t4, bm_lline, lo_lline, r01.x, r01.y, r23.x, r23.y);
+                }
+
+                // ---- pan to the outputs (constant gains in this path) ----
+                {
+                    const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k); // gains of two lines: L,R,L,R
+                        if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
+                        if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
+                        if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
+                        if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
+                    }
+                }
+                if (act) {
+                    if (last) {
+                        if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
+                        else dst[pos] = o0;
+                    } else {
+                        mixbuf[pos] = o0;
+                        if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos] = o1;
+                    }
+                }
+                continue;
+            }
 
             wave_sync(); // ring stores of the previous tile precede the loads below (program order)
 
@@ -597,10 +902,16 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
             fade_count += todo;
             if (fade_count >= OALSFX_RV_FADE_SAMPLES) {
                 fade_count = OALSFX_RV_FADE_SAMPLES;
+                if (lane == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    cur_etap[j] = P.early_tap[j]; cur_eap[j] = P.early_ap_off[j]; cur_eline[j] = P.early_line_off[j];
-                    cur_ltap[j] = P.late_tap[j]; cur_lap[j] = P.late_ap_off[j]; cur_lline[j] = P.late_line_off[j];
+                    for (int j = 0; j < 4; ++j) {
+                        utu[ut::TAP4 + 0 + j] = 4u * static_cast<unsigned>(P.early_tap[j]);
+                        utu[ut::TAP4 + 4 + j] = 4u * static_cast<unsigned>(P.early_ap_off[j]);
+                        utu[ut::TAP4 + 8 + j] = 4u * static_cast<unsigned>(P.early_line_off[j]);
+                        utu[ut::TAP4 + 12 + j] = 4u * static_cast<unsigned>(P.late_tap[j]);
+                        utu[ut::TAP4 + 16 + j] = 4u * static_cast<unsigned>(P.late_ap_off[j]);
+                        utu[ut::TAP4 + 20 + j] = 4u * static_cast<unsigned>(P.late_line_off[j]);
+                    }
                 }
             }
         }
@@ -624,12 +935,9 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
         if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
         else S.early_cur_gain[q_line][q_chan] = g_cur;
     }
+    wave_sync();
+    if (lane < 24) (&S.cur_early_tap[0])[lane] = static_cast<int32_t>(utu[ut::TAP4 + lane] >> 2);
     if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            S.cur_early_tap[j] = cur_etap[j]; S.cur_early_ap_off[j] = cur_eap[j]; S.cur_early_line_off[j] = cur_eline[j];
-            S.cur_late_tap[j] = cur_ltap[j]; S.cur_late_ap_off[j] = cur_lap[j]; S.cur_late_line_off[j] = cur_lline[j];
-        }
         S.mod_index = mod_index; S.mod_range = mod_range; S.mod_filter = mod_filter;
         S.fade_count = fade_count; S.offset = offset;
         SS.seen_seq = SP.update_seq;
