@@ -70,6 +70,7 @@ struct oalsfx_batch {
     float* d_tail = nullptr;
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
+    int* d_progress = nullptr;                    // [n*slots] hand-off between the steady-state and the general reverb kernel
     int list_offset[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     std::map<size_t, RingPool> pools;
@@ -315,6 +316,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.source = b->d_source;
     ctx.src_tail = b->d_tail;
     ctx.mixbuf = b->d_mixbuf;
+    ctx.progress = b->d_progress;
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
@@ -388,6 +390,8 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_tail), static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float)), "hipMalloc(tail)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_tail, 0, static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float), b->stream), "hipMemsetAsync(tail)");
     if (!ok) {
@@ -406,7 +410,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_tail);
-    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }

@@ -23,6 +23,7 @@ struct KernelCtx {
     const float* src;                   // [instance][frames][channels] interleaved input of this chunk
     float* dst;                         // [instance][frames][channels] interleaved output of this chunk
     float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
+    int* progress;                      // [instance][slots]: frames of this chunk already done by a steady-state kernel
     int slots;
     int channels;
     int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
