@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
         if (lane == 0) utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
         wave_sync();
         const unsigned tp = (lane < 24) ? utu[ut::TAP4 + lane] : 0xFFFFFFFFu;
-        const unsigned need = 256u + ((lane >> 2) == 3 ? utu[ut::FEED4] : 0u);
+        const unsigned need = 512u + ((lane >> 2) == 3 ? utu[ut::FEED4] : 0u); // 128 samples: this tile and the prefetched next one
         go = __ballot(tp >= need) == ~0ULL;
     }
     if (!go) {
@@ -310,6 +310,38 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
     const float b2a = 0.288675134595F;
     wave_sync();
 
+    // Software pipeline: the taps and the input frame of tile k+1 are requested before tile k is computed, so HBM
+    // latency overlaps arithmetic inside one wavefront.  Legal because every tap is at least two tiles away.
+    v4f n_e, n_a, n_el, n_lt, n_la, n_ll;
+    float n_in0 = 0.0F, n_in1 = 0.0F;
+    auto issue_loads = [&](unsigned t4x, int posx) {
+        auto load4 = [&](int group, int r) -> v4f {
+            const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+            const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+            const unsigned bm = utu[ut::BMASK + r];
+            v4f v;
+            v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
+            v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
+            v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
+            v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
+            return v;
+        };
+        const int px = min(posx, frames - 1); // a prefetch may run past a buffer whose tail this kernel will not process
+        if (CH == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
+            n_in0 = v.x; n_in1 = v.y;
+        } else {
+            n_in0 = src[px];
+        }
+        n_e = load4(0, OALSFX_RV_MAIN);
+        n_a = load4(1, OALSFX_RV_EARLY_AP);
+        n_el = load4(2, OALSFX_RV_EARLY_LINE);
+        n_lt = load4(3, OALSFX_RV_MAIN);
+        n_la = load4(4, OALSFX_RV_LATE_AP);
+        n_ll = load4(5, OALSFX_RV_LATE_LINE);
+    };
+    issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
+
     int base = 0;
     while (base < frames) {
         const int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
@@ -317,55 +349,32 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
         const float delta = 1.0F / static_cast<float>(frames - base);
         const float g_step = (g_tgt - g_cur) * delta;
         if (__ballot(q_valid && fabsf(g_step) > FLT_EPSILON) != 0ULL) break;
+        if (todo & 63) break; // partial tiles are left to the general kernel: here every lane is always active
 
         for (int done = 0; done < todo; done += 64) {
-            const int L = min(64, todo - done);
-            const bool act = lane < L;
+            constexpr int L = 64;
             const int t = offset + done + lane;
             const unsigned t4 = static_cast<unsigned>(t) << 2;
             const int pos = base + done + lane;
                 // ================= steady-state tile: packed arithmetic, constants from the LDS table =================
                 wave_sync(); // ring stores of the previous tile precede the loads below (program order)
-                // ring constants are re-read from the LDS table at every use (broadcast ds_read, no VALU, short-lived)
-                auto load4 = [&](int group, int r) -> v4f {
-                    const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
-                    const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
-                    const unsigned bm = utu[ut::BMASK + r];
-                    v4f v;
-                    v.x = ld(slab_b, ((t4 - d.x) & bm) | lo.x);
-                    v.y = ld(slab_b, ((t4 - d.y) & bm) | lo.y);
-                    v.z = ld(slab_b, ((t4 - d.z) & bm) | lo.z);
-                    v.w = ld(slab_b, ((t4 - d.w) & bm) | lo.w);
-                    return v;
-                };
                 auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
-                    if (act) {
-                        const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
-                        const unsigned wp = p4 & utu[ut::BMASK + r];
-                        st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
-                    }
+                    const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+                    const unsigned wp = p4 & utu[ut::BMASK + r];
+                    st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
                 };
-                // ---- loads: nothing of this tile is needed to issue them ----
-                float in0 = 0.0F, in1 = 0.0F;
-                if (act) {
-                    if (CH == 2) {
-                        const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(pos) * 2);
-                        in0 = v.x; in1 = v.y;
-                    } else {
-                        in0 = src[pos];
-                    }
+                // ---- this tile's inputs were requested one tile ago; request the next tile's now ----
+                const float in0 = n_in0, in1 = n_in1;
+                const v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
+                {
+                    const int next_pos = base + done + L;            // chunk-relative positions and sample times are contiguous
+                    if (next_pos < frames) issue_loads(t4 + (static_cast<unsigned>(L) << 2), pos + L);
                 }
                 float o0 = 0.0F, o1 = 0.0F;
-                if (!first && act) {
+                if (!first) {
                     o0 = mixbuf[pos];
                     if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
                 }
-                const v4f p_e = load4(0, OALSFX_RV_MAIN);
-                const v4f p_a = load4(1, OALSFX_RV_EARLY_AP);
-                const v4f p_el = load4(2, OALSFX_RV_EARLY_LINE);
-                const v4f p_lt = load4(3, OALSFX_RV_MAIN);
-                const v4f p_la = load4(4, OALSFX_RV_LATE_AP);
-                const v4f p_ll = load4(5, OALSFX_RV_LATE_LINE);
                 // ---- input: dry mix, B-format send, A-format ----
                 const float in[2] = {in0, in1};
                 if (first) {
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
                         if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
                     }
                 }
-                if (act) {
+                {
                     if (last) {
                         if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
                         else dst[pos] = o0;
