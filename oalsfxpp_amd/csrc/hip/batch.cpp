@@ -295,7 +295,7 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
     }
     if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) {
         static const int debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
-        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (debug_flags << 8), stream);
+        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | (debug_flags << 8), stream);
     }
     else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
     if (b->timing) {

@@ -34,6 +34,7 @@ struct KernelCtx {
 enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
+    kEax = 4,   // reverb kernels: the list holds EAX reverb instances (second input shelf active)
 };
 
 constexpr int kWave = 64;

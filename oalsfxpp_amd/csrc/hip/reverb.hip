@@ -568,6 +568,399 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
     }
 }
 
+
+// =================================================================================================
+// Cooperative steady-state kernel: like k_reverb_steady (one wavefront per instance, 64 sample times per
+// tile, packed arithmetic, prefetched taps), but the serial filter recurrences of the four instances of a
+// workgroup are run together: for every chain phase one wavefront executes the recurrences of all 16
+// (instance, line) pairs on 16 lanes while its siblings wait at a workgroup barrier.  The recurrences are
+// about 70 % of the vector instructions of the per-wave version (4 active lanes each); sharing them cuts
+// that part by four.  A workgroup takes this path only with full 64-frame tiles; an instance that is not
+// in its steady state sits the phases out (empty chain range) and is left to the general kernel.
+//
+// Barriers are raw s_barrier preceded by s_waitcnt lgkmcnt(0) only: LDS traffic must be complete, global
+// loads (the prefetch of the next tile) and ring stores stay in flight across them.
+// =================================================================================================
+namespace coop {
+enum { LPX0, LPX1, LPY0, LPY1, HPY0, HPY1, T60X, T60O1, T60O2, LP_A1, LP_A2, HP_A1, HP_A2, T_L2, T_H2, T_MID, SIZE };
+}
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int CH>
+__global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+{
+    static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
+    constexpr int kFloats = kGroups * 4 * kRow + ut::SIZE;
+    __shared__ __attribute__((aligned(16))) float lds_all[4][kFloats];
+    __shared__ float chain_all[4][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
+    __shared__ int go_all[4];
+
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + wib;
+    const bool valid = w < count;
+    const int lane = threadIdx.x & 63;
+    const int frames = ctx.frames;
+    const bool eax = (flags & kEax) != 0;
+    const bool first = (flags & kFirst) != 0;
+    const bool last = (flags & kLast) != 0;
+
+    float* lds = lds_all[wib];
+    auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
+    float* utf = lds + kGroups * 4 * kRow;
+    unsigned* utu = reinterpret_cast<unsigned*>(utf);
+
+    const int inst = __builtin_amdgcn_readfirstlane(list[valid ? w : 0]);
+    const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
+    typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
+    ConstSlotParams& SP = *(ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
+    const auto& P = SP.u.reverb;
+    oalsfx_slot_state& SS = ctx.state[sidx];
+    oalsfx_reverb_state& S = SS.u.reverb;
+    GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
+
+    // ---- is this instance in its steady state for the whole buffer? (see k_reverb_steady) ----
+    bool go = valid && (frames & 63) == 0 && (SS.seen_seq == SP.update_seq) && (S.fade_count >= OALSFX_RV_FADE_SAMPLES) &&
+              (P.mod_depth == 0.0F) && (S.mod_filter == 0.0F);
+    const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
+    const bool q_valid = lane < 8 * CH;
+    float g_cur = 0.0F;
+    if (go) {
+        float g_tgt = 0.0F;
+        if (q_valid) {
+            g_cur = q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan];
+            g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
+        }
+        // the last chunk of the buffer has the smallest ramp counter, hence the largest step: no ramp there, no ramp anywhere
+        const int last_chunk = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
+        const float step = (g_tgt - g_cur) * (1.0F / static_cast<float>(last_chunk));
+        if (__ballot(q_valid && fabsf(step) > FLT_EPSILON) != 0ULL) go = false;
+    }
+    if (go) {
+        if (lane < 24) utu[ut::TAP4 + lane] = 4u * static_cast<unsigned>((&S.cur_early_tap[0])[lane]);
+        if (lane == 0) utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
+        wave_sync();
+        const unsigned tp = (lane < 24) ? utu[ut::TAP4 + lane] : 0xFFFFFFFFu;
+        const unsigned need = 512u + ((lane >> 2) == 3 ? utu[ut::FEED4] : 0u);
+        go = __ballot(tp >= need) == ~0ULL;
+    }
+    if (lane == 0) {
+        go_all[wib] = go ? 1 : 0;
+        if (valid && !go) ctx.progress[sidx] = 0;
+    }
+
+    unsigned aud_dir = 0, aud_aux = 0, aud_out = 0;
+    int offset = 0;
+    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
+    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
+    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * CH * OALSFX_MAX_CHUNK : nullptr;
+    const float b2a = 0.288675134595F;
+    if (go) {
+        // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
+        if (lane < 20) {
+            const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb;
+            const int r = lane >> 2, j = lane & 3;
+            utu[ut::LO + lane] = static_cast<unsigned>(PG.ring_off[r] + j * PG.ring_len[r]) << 2;
+            if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(PG.ring_len[lane] - 1) << 2;
+            if (lane < 4) {
+                utf[ut::ECOEF + lane] = PG.early_tap_coeff[lane];
+                utf[ut::ELCOEF + lane] = PG.early_line_coeff[lane];
+                utf[ut::TL0 + lane] = PG.t60_lf[lane][0];
+                utf[ut::TL1 + lane] = PG.t60_lf[lane][1];
+                utf[ut::TH0 + lane] = PG.t60_hf[lane][0];
+                utf[ut::TH1 + lane] = PG.t60_hf[lane][1];
+                float* ch = chain_all[wib][lane];
+                ch[coop::LPX0] = S.lp[lane].x[0]; ch[coop::LPX1] = S.lp[lane].x[1];
+                ch[coop::LPY0] = S.lp[lane].y[0]; ch[coop::LPY1] = S.lp[lane].y[1];
+                ch[coop::HPY0] = S.hp[lane].y[0]; ch[coop::HPY1] = S.hp[lane].y[1];
+                ch[coop::T60X] = S.t60[lane][0][0]; ch[coop::T60O1] = S.t60[lane][0][1]; ch[coop::T60O2] = S.t60[lane][1][1];
+                ch[coop::LP_A1] = PG.lp.a1; ch[coop::LP_A2] = PG.lp.a2; ch[coop::HP_A1] = PG.hp.a1; ch[coop::HP_A2] = PG.hp.a2;
+                ch[coop::T_L2] = PG.t60_lf[lane][2]; ch[coop::T_H2] = PG.t60_hf[lane][2]; ch[coop::T_MID] = PG.t60_mid[lane];
+            }
+            const oalsfx_source_params& SG = ctx.source[inst];
+            if (lane < 4) utf[ut::GDIR + lane] = SG.direct.gains[lane >> 1][lane & 1];
+            if (lane < 8) utf[ut::GAUX + lane] = SG.aux[slot].gains[lane >> 2][lane & 3];
+        }
+        if (lane == 0) {
+            utf[ut::MISC + 0] = P.density_gain; utf[ut::MISC + 1] = P.ap_feed_coeff; utf[ut::MISC + 2] = P.mix_x; utf[ut::MISC + 3] = P.mix_y;
+            utf[ut::LPB + 0] = P.lp.b0; utf[ut::LPB + 1] = P.lp.b1; utf[ut::LPB + 2] = P.lp.b2; utf[ut::LPB + 3] = 0.0F;
+            utf[ut::HPB + 0] = P.hp.b0; utf[ut::HPB + 1] = P.hp.b1; utf[ut::HPB + 2] = P.hp.b2; utf[ut::HPB + 3] = 0.0F;
+        }
+        if (q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
+        typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
+        ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int o = 0; o < CH; ++o) aud_dir |= audible(SRC.direct.gains[c][o]) ? 1u << (c * 2 + o) : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aud_aux |= audible(SRC.aux[slot].gains[c][k]) ? 1u << (c * 4 + k) : 0u;
+        }
+        aud_out = static_cast<unsigned>(__ballot(q_valid && audible(g_cur)));
+        if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
+                                ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
+        offset = S.offset;
+    }
+
+    // Software pipeline: inputs of tile k+1 are requested before tile k is computed (every tap is >= 2 tiles away).
+    v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
+    float n_in0 = 0.0F, n_in1 = 0.0F;
+    auto issue_loads = [&](unsigned t4x, int posx) {
+        auto load4 = [&](int group, int r) -> v4f {
+            const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+            const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+            const unsigned bm = utu[ut::BMASK + r];
+            v4f v;
+            v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
+            v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
+            v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
+            v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
+            return v;
+        };
+        const int px = min(posx, frames - 1);
+        if (CH == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
+            n_in0 = v.x; n_in1 = v.y;
+        } else {
+            n_in0 = src[px];
+        }
+        n_e = load4(0, OALSFX_RV_MAIN);
+        n_a = load4(1, OALSFX_RV_EARLY_AP);
+        n_el = load4(2, OALSFX_RV_EARLY_LINE);
+        n_lt = load4(3, OALSFX_RV_MAIN);
+        n_la = load4(4, OALSFX_RV_LATE_AP);
+        n_ll = load4(5, OALSFX_RV_LATE_LINE);
+    };
+    auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
+        const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+        const unsigned wp = p4 & utu[ut::BMASK + r];
+        st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
+    };
+    // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 16
+    const int cw = (lane >> 2) & 3, cc = lane & 3;
+    float* crow0 = lds_all[cw] + (0 * 4 + cc) * kRow;
+    float* crow1 = lds_all[cw] + (1 * 4 + cc) * kRow;
+    float* crow2 = lds_all[cw] + (2 * 4 + cc) * kRow;
+    float* cdat = chain_all[cw][cc];
+
+    lds_barrier(); // tables, chain data and go flags are in place
+    const bool chain_on = (lane < 16) && go_all[cw] != 0;
+    if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
+
+    const int tiles = frames >> 6;
+    for (int tile = 0; tile < tiles; ++tile) {
+        const int pos = (tile << 6) + lane;
+        const unsigned t4 = static_cast<unsigned>(offset + pos) << 2;
+        float o0 = 0.0F, o1 = 0.0F;
+        v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
+
+        // ---------------- P1: inputs, A-format, feed-forward half of the first shelf ----------------
+        if (go) {
+            const float in[2] = {n_in0, n_in1};
+            if (tile + 1 < tiles) issue_loads(t4 + 256u, pos + 64);
+            if (!first) {
+                o0 = mixbuf[pos];
+                if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
+            } else {
+                const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
+                const float g[4] = {gd.x, gd.y, gd.z, gd.w};
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (aud_dir & (1u << (c * 2 + 0))) o0 += in[c] * g[c * 2 + 0];
+                    if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) o1 += in[c] * g[c * 2 + 1];
+                }
+            }
+            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
+                const float g[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (aud_aux & (1u << (c * 4 + k))) wet[k] += in[c] * g[k];
+            }
+            v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
+            a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
+            a23 = a23 + wet[0] * v2f{b2a, b2a}; a23 = a23 + wet[1] * v2f{b2a, -b2a}; a23 = a23 + wet[2] * v2f{-b2a, b2a}; a23 = a23 + wet[3] * v2f{-b2a, -b2a};
+            if (lane < 4) {
+                const float* ch = chain_all[wib][lane];
+                row(0, lane)[3] = ch[coop::LPX0]; row(0, lane)[2] = ch[coop::LPX1];
+            }
+            row(0, 0)[4 + lane] = a01.x; row(0, 1)[4 + lane] = a01.y; row(0, 2)[4 + lane] = a23.x; row(0, 3)[4 + lane] = a23.y;
+            wave_sync();
+            {
+                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::LPB);
+                const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
+                const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
+                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
+            }
+            if (lane < 4) {
+                float* ch = chain_all[wib][lane];
+                ch[coop::LPX1] = row(0, lane)[4 + 62]; ch[coop::LPX0] = row(0, lane)[4 + 63];
+            }
+        }
+        lds_barrier();
+        // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
+        if (wib == 0 && chain_on) {
+            float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
+            crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
+            biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
+        }
+        lds_barrier();
+        int xg = 2;
+        if (eax) {
+            // ---------------- P2: feed-forward half of the second shelf ----------------
+            if (go) {
+                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
+                const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
+                const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
+                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
+            }
+            lds_barrier();
+            // ---------------- C2 (wave 1) ----------------
+            if (wib == 1 && chain_on) {
+                float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
+                biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
+                cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
+            }
+            lds_barrier();
+            xg = 0;
+        }
+        // ---------------- P3: main delay write, early reflections, late taps, T60 first feed-forward ----------------
+        v2f e01 = {0, 0}, e23 = {0, 0};
+        float dg = 0.0F, ac = 0.0F, sx = 0.0F, sy = 0.0F;
+        if (go) {
+            store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
+            wave_sync();
+            const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
+            dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
+            const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
+            const v4f elc = *reinterpret_cast<const v4f*>(utf + ut::ELCOEF);
+            const v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
+            const v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
+            const v2f v01 = v2f{p_a.x, p_a.y} - (ac * f01);
+            const v2f v23 = v2f{p_a.z, p_a.w} - (ac * f23);
+            v2f g01 = f01 + (ac * v01);
+            v2f g23 = f23 + (ac * v23);
+            scatter2(g01, g23, sx, sy);
+            store4(t4, OALSFX_RV_EARLY_AP, g01.x, g01.y, g23.x, g23.y);
+            store4(t4, OALSFX_RV_EARLY_LINE, v23.y, v23.x, v01.y, v01.x);
+            e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
+            e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
+            {
+                v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
+                scatter2(r01, r23, sx, sy);
+                store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
+            }
+            const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
+            const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
+            if (lane < 4) row(0, lane)[3] = chain_all[wib][lane][coop::T60X];
+            row(0, 0)[4 + lane] = u01.x; row(0, 1)[4 + lane] = u01.y; row(0, 2)[4 + lane] = u23.x; row(0, 3)[4 + lane] = u23.y;
+            wave_sync();
+            {
+                const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TL0);
+                const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TL1);
+                const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
+                const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
+                const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
+                const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
+                row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+            }
+            if (lane < 4) chain_all[wib][lane][coop::T60X] = row(0, lane)[4 + 63];
+        }
+        lds_barrier();
+        // ---------------- C3 (wave 2): first T60 section ----------------
+        if (wib == 2 && chain_on) {
+            float prev = cdat[coop::T60O1];
+            crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
+            first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
+            cdat[coop::T60O1] = prev;
+        }
+        lds_barrier();
+        // ---------------- P4: second T60 feed-forward ----------------
+        if (go) {
+            const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
+            const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TH1);
+            const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
+            const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
+            const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
+            const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
+            row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+        }
+        lds_barrier();
+        // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
+        if (wib == 3 && chain_on) {
+            float prev = cdat[coop::T60O2];
+            first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+            cdat[coop::T60O2] = prev;
+        }
+        lds_barrier();
+        // ---------------- P5: late all-pass, ring writes, outputs ----------------
+        if (go) {
+            const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
+            const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
+            const v2f l01 = v2f{p_la.x, p_la.y} - (ac * i01);
+            const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
+            v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
+            scatter2(q01, q23, sx, sy);
+            store4(t4, OALSFX_RV_LATE_AP, q01.x, q01.y, q23.x, q23.y);
+            v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
+            scatter2(r01, r23, sx, sy);
+            store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
+            const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k);
+                if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
+                if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
+                if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
+                if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
+            }
+            if (last) {
+                if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
+                else dst[pos] = o0;
+            } else {
+                mixbuf[pos] = o0;
+                if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos] = o1;
+            }
+            wave_sync(); // ring stores of this tile precede the loads of the tile after next (program order)
+        }
+    }
+
+    // ---- hand the state back ----
+    if (go) {
+        if (lane < 4) {
+            const float* ch = chain_all[wib][lane];
+            S.lp[lane].x[0] = ch[coop::LPX0]; S.lp[lane].x[1] = ch[coop::LPX1];
+            S.lp[lane].y[0] = ch[coop::LPY0]; S.lp[lane].y[1] = ch[coop::LPY1];
+            if (eax) {
+                S.hp[lane].x[0] = ch[coop::LPY0]; S.hp[lane].x[1] = ch[coop::LPY1];
+                S.hp[lane].y[0] = ch[coop::HPY0]; S.hp[lane].y[1] = ch[coop::HPY1];
+            }
+            S.t60[lane][0][0] = ch[coop::T60X]; S.t60[lane][0][1] = ch[coop::T60O1];
+            S.t60[lane][1][0] = ch[coop::T60O1]; S.t60[lane][1][1] = ch[coop::T60O2];
+        }
+        if (lane == 0) {
+            S.mod_index = static_cast<int>((static_cast<long long>(S.mod_index) + frames) % S.mod_range);
+            S.offset = offset + frames;
+            ctx.progress[sidx] = frames;
+        }
+        if (first && lane < CH) {
+            float* tail = ctx.src_tail + (static_cast<size_t>(inst) * CH + lane) * 2;
+            tail[0] = src[static_cast<size_t>(frames - 1) * CH + lane];
+            tail[1] = src[static_cast<size_t>(frames - 2) * CH + lane];
+        }
+    }
+}
+
 template <int CH>
 __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
@@ -1135,10 +1528,16 @@ void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, i
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    const bool steady_first = ctx.progress != nullptr && ctx.channels <= 2 && !(flags >> 8 & 8);
+    const int dbg = flags >> 8; // timing experiments only: 8 = no steady-state kernel, 16 = per-wave (non-cooperative) steady kernel
+    const bool steady_first = ctx.progress != nullptr && ctx.channels <= 2 && !(dbg & 8);
     if (steady_first) {
-        if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
-        else hipLaunchKernelGGL(k_reverb_steady<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
+        if (dbg & 16) {
+            if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
+            else hipLaunchKernelGGL(k_reverb_steady<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
+        } else {
+            if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady_coop<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
+            else hipLaunchKernelGGL(k_reverb_steady_coop<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
+        }
     }
     KernelCtx general = ctx;
     if (!steady_first) general.progress = nullptr;
