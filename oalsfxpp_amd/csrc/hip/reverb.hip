@@ -748,6 +748,9 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
 
     lds_barrier(); // tables, chain data and go flags are in place
     const bool chain_on = (lane < 16) && go_all[cw] != 0;
+    // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
+    // put the same phase on the same SIMD
+    const int duty = (wib - static_cast<int>(blockIdx.x)) & 3;
     if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
 
     const int tiles = frames >> 6;
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
-        if (wib == 0 && chain_on) {
+        if (duty == 0 && chain_on) {
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
             crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
             biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
             }
             lds_barrier();
             // ---------------- C2 (wave 1) ----------------
-            if (wib == 1 && chain_on) {
+            if (duty == 1 && chain_on) {
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
                 biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C3 (wave 2): first T60 section ----------------
-        if (wib == 2 && chain_on) {
+        if (duty == 2 && chain_on) {
             float prev = cdat[coop::T60O1];
             crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
             first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
-        if (wib == 3 && chain_on) {
+        if (duty == 3 && chain_on) {
             float prev = cdat[coop::T60O2];
             first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
