@@ -590,17 +590,17 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CH>
-__global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+template <int CH, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
     constexpr int kFloats = kGroups * 4 * kRow + ut::SIZE;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][kFloats];
-    __shared__ float chain_all[4][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
-    __shared__ int go_all[4];
+    __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
+    __shared__ float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
+    __shared__ int go_all[NW];
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * 4 + wib;
+    const int w = blockIdx.x * NW + wib;
     const bool valid = w < count;
     const int lane = threadIdx.x & 63;
     const int frames = ctx.frames;
@@ -739,18 +739,18 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         const unsigned wp = p4 & utu[ut::BMASK + r];
         st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
     };
-    // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 16
-    const int cw = (lane >> 2) & 3, cc = lane & 3;
+    // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 4 * NW
+    const int cw = (lane >> 2) & (NW - 1), cc = lane & 3;
     float* crow0 = lds_all[cw] + (0 * 4 + cc) * kRow;
     float* crow1 = lds_all[cw] + (1 * 4 + cc) * kRow;
     float* crow2 = lds_all[cw] + (2 * 4 + cc) * kRow;
     float* cdat = chain_all[cw][cc];
 
     lds_barrier(); // tables, chain data and go flags are in place
-    const bool chain_on = (lane < 16) && go_all[cw] != 0;
+    const bool chain_on = (lane < 4 * NW) && go_all[cw] != 0;
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
     // put the same phase on the same SIMD
-    const int duty = (wib - static_cast<int>(blockIdx.x)) & 3;
+    const int duty = (wib - static_cast<int>(blockIdx.x)) & (NW - 1);
     if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
 
     const int tiles = frames >> 6;
@@ -764,6 +764,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         if (go) {
             const float in[2] = {n_in0, n_in1};
             if (tile + 1 < tiles) issue_loads(t4 + 256u, pos + 64);
+            __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
             if (!first) {
                 o0 = mixbuf[pos];
                 if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
-        if (duty == 0 && chain_on) {
+        if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
             crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
             biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
             }
             lds_barrier();
             // ---------------- C2 (wave 1) ----------------
-            if (duty == 1 && chain_on) {
+            if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
                 biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
@@ -881,7 +882,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C3 (wave 2): first T60 section ----------------
-        if (duty == 2 && chain_on) {
+        if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float prev = cdat[coop::T60O1];
             crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
             first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_coop(KernelCtx ctx, in
         }
         lds_barrier();
         // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
-        if (duty == 3 && chain_on) {
+        if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float prev = cdat[coop::T60O2];
             first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
@@ -1538,8 +1539,18 @@ void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, i
             if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
             else hipLaunchKernelGGL(k_reverb_steady<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
         } else {
-            if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady_coop<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
-            else hipLaunchKernelGGL(k_reverb_steady_coop<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
+            if (dbg & 64) {
+                const dim3 grid2((count + 1) / 2), block2(128);
+                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 2>), grid2, block2, 0, stream, ctx, slot, list, count, flags);
+                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 2>), grid2, block2, 0, stream, ctx, slot, list, count, flags);
+            } else if (dbg & 32) {
+                const dim3 grid8((count + 7) / 8), block8(512);
+                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 8>), grid8, block8, 0, stream, ctx, slot, list, count, flags);
+                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 8>), grid8, block8, 0, stream, ctx, slot, list, count, flags);
+            } else {
+                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, ctx, slot, list, count, flags);
+                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, ctx, slot, list, count, flags);
+            }
         }
     }
     KernelCtx general = ctx;
