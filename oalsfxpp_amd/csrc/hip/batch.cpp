@@ -58,6 +58,8 @@ struct oalsfx_batch {
     std::vector<float*> h_rings;                  // [n*slots]
     std::vector<size_t> ring_floats;              // [n*slots] size class of the slab held
     std::vector<uint8_t> inst_dirty;              // [n]
+    std::vector<int> since_update;                // [n*slots] frames mixed since the slot's last parameter update (capped)
+    int unsettled[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // reverb instances per list not yet believed steady
     std::vector<int> dirty_list;
     bool lists_dirty = true;
     bool filters_active = false;
@@ -152,17 +154,48 @@ void release_slab(oalsfx_batch* b, size_t idx)
     }
 }
 
+constexpr int kSettleFrames = 2 * OALSFX_RV_FADE_SAMPLES; // a cross-fade (128 frames) and the gain ramp of one call are over
+
+// Host-side belief about which reverb instances the steady-state kernel will fully process.  It only selects the
+// grid of the general kernel that follows (a speed hint); the kernels decide on the device from the real state.
+bool reverb_settled(const oalsfx_batch* b, size_t idx)
+{
+    const oalsfx_reverb_params& p = b->h_params[idx].u.reverb;
+    if (b->since_update[idx] < kSettleFrames || p.mod_depth != 0.0F) return false;
+    for (int j = 0; j < 4; ++j) {
+        if (p.early_tap[j] < 128 || p.early_ap_off[j] < 128 || p.early_line_off[j] < 128 || p.late_ap_off[j] < 128 ||
+            p.late_line_off[j] < 128 || p.late_tap[j] < p.late_feed_tap + 128)
+            return false;
+    }
+    return true;
+}
+
+void recount_unsettled(oalsfx_batch* b)
+{
+    int before = 0, after = 0;
+    for (int s = 0; s < b->slots; ++s)
+        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) { before += b->unsettled[s][t]; b->unsettled[s][t] = 0; }
+    for (int i = 0; i < b->n; ++i)
+        for (int s = 0; s < b->slots; ++s) {
+            const size_t idx = static_cast<size_t>(i) * b->slots + s;
+            const int t = b->h_params[idx].type;
+            if ((t == OALSFX_REVERB || t == OALSFX_EAX_REVERB) && !reverb_settled(b, idx)) { b->unsettled[s][t] += 1; ++after; }
+        }
+    if (after != before) b->lists_dirty = true; // the settled-first order of the reverb lists is stale
+}
+
 // Folds all pending property changes into descriptors, device state and the launch plan: what the
 // reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
 // plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
 bool sync_params(oalsfx_batch* b)
 {
-    if (b->dirty_list.empty()) return true;
+    if (b->dirty_list.empty() && !b->lists_dirty) return true;
     const size_t total = static_cast<size_t>(b->n) * b->slots;
     std::vector<uint8_t> up_params(total, 0), up_state(total, 0), up_source(b->n, 0);
     std::map<size_t, int> need; // size class -> slabs needed
     std::vector<size_t> restarted;
     bool any_type_change = false;
+    bool settle_dirty = false;
 
     for (int i : b->dirty_list) {
         InstanceHost& h = b->inst[i];
@@ -176,6 +209,8 @@ bool sync_params(oalsfx_batch* b)
             derive_slot(b->dev, h.active[s], p);
             p.update_seq = ++b->seq[idx];
             up_params[idx] = 1;
+            b->since_update[idx] = 0;
+            settle_dirty = true;
             if (h.slot_retyped[s]) {
                 h.slot_retyped[s] = false;
                 any_type_change = true;
@@ -258,8 +293,16 @@ bool sync_params(oalsfx_batch* b)
             for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) {
                 b->list_offset[s][t] = s * b->n + off;
                 int cnt = 0;
-                for (int i = 0; i < b->n; ++i)
-                    if (b->h_params[static_cast<size_t>(i) * b->slots + s].type == t) lists[s * b->n + off + cnt++] = i;
+                // reverb lists: instances believed steady first, so that the 4-instance workgroups of the kernel are
+                // (almost all) either fully steady or fully transitional; the order has no effect on results
+                const bool reverb = (t == OALSFX_REVERB || t == OALSFX_EAX_REVERB);
+                for (int pass = 0; pass < (reverb ? 2 : 1); ++pass)
+                    for (int i = 0; i < b->n; ++i) {
+                        const size_t idx = static_cast<size_t>(i) * b->slots + s;
+                        if (b->h_params[idx].type != t) continue;
+                        if (reverb && reverb_settled(b, idx) != (pass == 0)) continue;
+                        lists[s * b->n + off + cnt++] = i;
+                    }
                 b->list_count[s][t] = cnt;
                 off += cnt;
             }
@@ -269,6 +312,7 @@ bool sync_params(oalsfx_batch* b)
         if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return false;
         b->lists_dirty = false;
     }
+    if (settle_dirty) recount_unsettled(b);
     // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
     return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
 }
@@ -295,7 +339,8 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
     }
     if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) {
         static const int debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
-        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | (debug_flags << 8), stream);
+        const bool expect_steady = b->unsettled[slot][type] == 0 && (ctx.frames & 63) == 0;
+        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | (debug_flags << 8), expect_steady, stream);
     }
     else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
     if (b->timing) {
@@ -331,6 +376,12 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) launch_type(b, t, ctx, s, flags, stream);
         }
         done += n;
+    }
+    bool any = false;
+    for (int s = 0; s < b->slots && !any; ++s) any = b->unsettled[s][OALSFX_REVERB] || b->unsettled[s][OALSFX_EAX_REVERB];
+    if (any) {
+        for (int& f : b->since_update) f = std::min(f + frames, kSettleFrames);
+        recount_unsettled(b);
     }
     return b->hip_ok(hipGetLastError(), "kernel launch");
 }
@@ -378,6 +429,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->h_rings.assign(total, nullptr);
     b->ring_floats.assign(total, 0);
     b->inst_dirty.assign(n_instances, 0);
+    b->since_update.assign(total, 0);
     for (int i = 0; i < n_instances; ++i) {
         b->inst[i].initialize(effect_count);
         mark_dirty(b, i);

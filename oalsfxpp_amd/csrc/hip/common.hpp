@@ -35,12 +35,14 @@ enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
     kEax = 4,   // reverb kernels: the list holds EAX reverb instances (second input shelf active)
+    kDeferGeneral = 8, // steady-state reverb kernel: leave non-steady instances to the general kernel launched next
 };
 
 constexpr int kWave = 64;
 
 // ---- launchers (defined next to their kernels) ----
-void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+// expect_steady: host-side belief that every listed instance is in its steady state (speed hint only)
+void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream);
 void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
 

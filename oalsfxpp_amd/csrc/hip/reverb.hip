@@ -185,391 +185,6 @@ __device__ __forceinline__ void first_order_chain(const float* row_u, float* row
 
 
 // =================================================================================================
-// Steady-state kernel.  Handles, per instance, the leading part of the buffer for which nothing
-// transitional is going on: no tap cross-fade, no modulation, no output gain ramp, and every current tap
-// at least one tile away (true for every instance of the headline workload after its first buffer).
-// It stops at the first chunk that does not qualify, records how far it got in ctx.progress and leaves
-// the rest of the buffer to the general kernel k_reverb, which is launched right after it on the same
-// list.  Keeping this path in its own kernel keeps its register footprint small: packed fp32
-// arithmetic, instance constants in an LDS table, 24 tap loads in flight per tile and no spills.
-// =================================================================================================
-template <int CH>
-__global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
-{
-    static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
-    constexpr int kFloats = kGroups * 4 * kRow + ut::SIZE;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][kFloats];
-
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * 4 + wave_in_block;
-    if (w >= count) return;
-    const int lane = threadIdx.x & 63;
-
-    float* lds = lds_all[wave_in_block];
-    auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
-    float* utf = lds + kGroups * 4 * kRow;
-    unsigned* utu = reinterpret_cast<unsigned*>(utf);
-
-    const int inst = __builtin_amdgcn_readfirstlane(list[w]);
-    const int frames = ctx.frames;
-    const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
-    typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
-    ConstSlotParams& SP = *(ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
-    const auto& P = SP.u.reverb;
-    oalsfx_slot_state& SS = ctx.state[sidx];
-    oalsfx_reverb_state& S = SS.u.reverb;
-    GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
-    const bool first = (flags & kFirst) != 0;
-    const bool last = (flags & kLast) != 0;
-    const bool eax = P.is_eax != 0;
-
-    // A pending parameter update (new update_seq) may start a cross-fade: not steady, leave everything to the general kernel.
-    // Likewise an unfinished cross-fade, a running modulator or a moving modulation-depth smoother.
-    const bool steady = (SS.seen_seq == SP.update_seq) && (S.fade_count >= OALSFX_RV_FADE_SAMPLES) && (P.mod_depth == 0.0F) &&
-                        (S.mod_filter == 0.0F);
-    // output gains: chain q = (stage*4 + line)*CH + channel lives in lane q; a gain that still moves towards its target
-    // means a ramp (reference MixHelpers::mix, src/oalsfxpp.cpp:2762-2786), also left to the general kernel
-    const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
-    const bool q_valid = lane < 8 * CH;
-    float g_cur = 0.0F, g_tgt = 0.0F;
-    if (q_valid) {
-        g_cur = q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan];
-        g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
-    }
-    // the ramp test of the first chunk (counter = frames); later chunks of the same buffer use a smaller counter, i.e. a
-    // larger step for the same difference, so they are re-tested below
-    bool go = steady;
-    if (go) {
-        if (lane < 24) utu[ut::TAP4 + lane] = 4u * static_cast<unsigned>((&S.cur_early_tap[0])[lane]);
-        if (lane == 0) utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
-        wave_sync();
-        const unsigned tp = (lane < 24) ? utu[ut::TAP4 + lane] : 0xFFFFFFFFu;
-        const unsigned need = 512u + ((lane >> 2) == 3 ? utu[ut::FEED4] : 0u); // 128 samples: this tile and the prefetched next one
-        go = __ballot(tp >= need) == ~0ULL;
-    }
-    if (!go) {
-        if (lane == 0) ctx.progress[sidx] = 0;
-        return;
-    }
-
-    // ---- per-wave table of instance constants in LDS (see namespace ut) ----
-    if (lane < 20) {
-        const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb;
-        const int r = lane >> 2, j = lane & 3;
-        utu[ut::LO + lane] = static_cast<unsigned>(PG.ring_off[r] + j * PG.ring_len[r]) << 2;
-        if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(PG.ring_len[lane] - 1) << 2;
-        if (lane < 4) {
-            utf[ut::ECOEF + lane] = PG.early_tap_coeff[lane];
-            utf[ut::ELCOEF + lane] = PG.early_line_coeff[lane];
-            utf[ut::TL0 + lane] = PG.t60_lf[lane][0];
-            utf[ut::TL1 + lane] = PG.t60_lf[lane][1];
-            utf[ut::TH0 + lane] = PG.t60_hf[lane][0];
-            utf[ut::TH1 + lane] = PG.t60_hf[lane][1];
-            utf[ut::TL2 + lane] = PG.t60_lf[lane][2];
-            utf[ut::TH2 + lane] = PG.t60_hf[lane][2];
-            utf[ut::TMID + lane] = PG.t60_mid[lane];
-        }
-        const oalsfx_source_params& SG = ctx.source[inst];
-        if (lane < 4) utf[ut::GDIR + lane] = SG.direct.gains[lane >> 1][lane & 1];
-        if (lane < 8) utf[ut::GAUX + lane] = SG.aux[slot].gains[lane >> 2][lane & 3];
-    }
-    if (lane == 0) {
-        utf[ut::MISC + 0] = P.density_gain; utf[ut::MISC + 1] = P.ap_feed_coeff; utf[ut::MISC + 2] = P.mix_x; utf[ut::MISC + 3] = P.mix_y;
-        utf[ut::LPB + 0] = P.lp.b0; utf[ut::LPB + 1] = P.lp.b1; utf[ut::LPB + 2] = P.lp.b2; utf[ut::LPB + 3] = 0.0F;
-        utf[ut::HPB + 0] = P.hp.b0; utf[ut::HPB + 1] = P.hp.b1; utf[ut::HPB + 2] = P.hp.b2; utf[ut::HPB + 3] = 0.0F;
-    }
-    if (q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
-    // audible gains as bit masks: bit c*2+o for the dry mix, bit c*4+k for the B-format send, bit 2*(stage*4+line)+channel for the outputs
-    unsigned aud_dir = 0, aud_aux = 0;
-    {
-        typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
-        ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-            for (int o = 0; o < CH; ++o) aud_dir |= audible(SRC.direct.gains[c][o]) ? 1u << (c * 2 + o) : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) aud_aux |= audible(SRC.aux[slot].gains[c][k]) ? 1u << (c * 4 + k) : 0u;
-        }
-    }
-    unsigned aud_out = static_cast<unsigned>(__ballot(q_valid && audible(g_cur)));
-    if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
-                            ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
-
-    // ---- chain lanes (0..3, one per line): filter histories in registers ----
-    const int cl = lane & 3;
-    float lpx0 = S.lp[cl].x[0], lpx1 = S.lp[cl].x[1], lpy0 = S.lp[cl].y[0], lpy1 = S.lp[cl].y[1];
-    float hpy0 = S.hp[cl].y[0], hpy1 = S.hp[cl].y[1];
-    float t60_x = S.t60[cl][0][0], t60_o1 = S.t60[cl][0][1], t60_o1b = S.t60[cl][1][0], t60_o2 = S.t60[cl][1][1];
-    int offset = S.offset, mod_index = S.mod_index;
-    const int mod_range = S.mod_range;
-
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
-    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
-    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * CH * OALSFX_MAX_CHUNK : nullptr;
-    const float b2a = 0.288675134595F;
-    wave_sync();
-
-    // Software pipeline: the taps and the input frame of tile k+1 are requested before tile k is computed, so HBM
-    // latency overlaps arithmetic inside one wavefront.  Legal because every tap is at least two tiles away.
-    v4f n_e, n_a, n_el, n_lt, n_la, n_ll;
-    float n_in0 = 0.0F, n_in1 = 0.0F;
-    auto issue_loads = [&](unsigned t4x, int posx) {
-        auto load4 = [&](int group, int r) -> v4f {
-            const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
-            const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
-            const unsigned bm = utu[ut::BMASK + r];
-            v4f v;
-            v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
-            v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
-            v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
-            v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
-            return v;
-        };
-        const int px = min(posx, frames - 1); // a prefetch may run past a buffer whose tail this kernel will not process
-        if (CH == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
-            n_in0 = v.x; n_in1 = v.y;
-        } else {
-            n_in0 = src[px];
-        }
-        n_e = load4(0, OALSFX_RV_MAIN);
-        n_a = load4(1, OALSFX_RV_EARLY_AP);
-        n_el = load4(2, OALSFX_RV_EARLY_LINE);
-        n_lt = load4(3, OALSFX_RV_MAIN);
-        n_la = load4(4, OALSFX_RV_LATE_AP);
-        n_ll = load4(5, OALSFX_RV_LATE_LINE);
-    };
-    issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
-
-    int base = 0;
-    while (base < frames) {
-        const int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
-        // gain ramp test of this chunk (MixHelpers::mix: step = (target - current) / (frames - base))
-        const float delta = 1.0F / static_cast<float>(frames - base);
-        const float g_step = (g_tgt - g_cur) * delta;
-        if (__ballot(q_valid && fabsf(g_step) > FLT_EPSILON) != 0ULL) break;
-        if (todo & 63) break; // partial tiles are left to the general kernel: here every lane is always active
-
-        for (int done = 0; done < todo; done += 64) {
-            constexpr int L = 64;
-            const int t = offset + done + lane;
-            const unsigned t4 = static_cast<unsigned>(t) << 2;
-            const int pos = base + done + lane;
-                // ================= steady-state tile: packed arithmetic, constants from the LDS table =================
-                wave_sync(); // ring stores of the previous tile precede the loads below (program order)
-                auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
-                    const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
-                    const unsigned wp = p4 & utu[ut::BMASK + r];
-                    st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
-                };
-                // ---- this tile's inputs were requested one tile ago; request the next tile's now ----
-                const float in0 = n_in0, in1 = n_in1;
-                const v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
-                {
-                    const int next_pos = base + done + L;            // chunk-relative positions and sample times are contiguous
-                    if (next_pos < frames) issue_loads(t4 + (static_cast<unsigned>(L) << 2), pos + L);
-                }
-                float o0 = 0.0F, o1 = 0.0F;
-                if (!first) {
-                    o0 = mixbuf[pos];
-                    if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
-                }
-                // ---- input: dry mix, B-format send, A-format ----
-                const float in[2] = {in0, in1};
-                if (first) {
-                    const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
-                    const float g[4] = {gd.x, gd.y, gd.z, gd.w};
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        if (aud_dir & (1u << (c * 2 + 0))) o0 += in[c] * g[c * 2 + 0];
-                        if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) o1 += in[c] * g[c * 2 + 1];
-                    }
-                }
-                float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
-                    const float g[4] = {ga.x, ga.y, ga.z, ga.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (aud_aux & (1u << (c * 4 + k))) wet[k] += in[c] * g[k];
-                }
-                v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
-                a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
-                a23 = a23 + wet[0] * v2f{b2a, b2a}; a23 = a23 + wet[1] * v2f{b2a, -b2a}; a23 = a23 + wet[2] * v2f{-b2a, b2a}; a23 = a23 + wet[3] * v2f{-b2a, -b2a};
-
-                // ---- input shelves: group 0 = a, 1 = feed-forward sums, 2 = lp output; then hp: 2 -> 1 -> 0 ----
-                if (lane < 4) {
-                    row(0, lane)[3] = lpx0; row(0, lane)[2] = lpx1;
-                    row(2, lane)[3] = lpy0; row(2, lane)[2] = lpy1;
-                }
-                row(0, 0)[4 + lane] = a01.x; row(0, 1)[4 + lane] = a01.y; row(0, 2)[4 + lane] = a23.x; row(0, 3)[4 + lane] = a23.y;
-                wave_sync();
-                {
-                    const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::LPB);
-                    const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
-                    const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
-                    const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
-                    const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
-                    row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
-                }
-                wave_sync();
-                if (lane < 4) {
-                    const float* ra = row(0, lane);
-                    const float nx1 = ra[4 + L - 2], nx0 = ra[4 + L - 1];
-                    lpx1 = nx1; lpx0 = nx0;
-                    biquad_chain(row(1, lane), row(2, lane), L, P.lp.a1, P.lp.a2, lpy0, lpy1);
-                }
-                wave_sync();
-                int xg = 2;
-                if (eax) {
-                    const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
-                    const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
-                    const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
-                    const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
-                    const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
-                    row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
-                    wave_sync();
-                    if (lane < 4) biquad_chain(row(1, lane), row(0, lane), L, P.hp.a1, P.hp.a2, hpy0, hpy1);
-                    wave_sync();
-                    xg = 0;
-                }
-                store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
-                wave_sync();
-
-                // ---- early reflections ----
-                const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC); // density gain, all-pass coefficient, mix x, mix y
-                const float dg = misc.x, ac = misc.y, sx = misc.z, sy = misc.w;
-                const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
-                const v4f elc = *reinterpret_cast<const v4f*>(utf + ut::ELCOEF);
-                v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
-                v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
-                v2f v01 = v2f{p_a.x, p_a.y} - (ac * f01);
-                v2f v23 = v2f{p_a.z, p_a.w} - (ac * f23);
-                v2f g01 = f01 + (ac * v01);
-                v2f g23 = f23 + (ac * v23);
-                scatter2(g01, g23, sx, sy);
-                store4(t4, OALSFX_RV_EARLY_AP, g01.x, g01.y, g23.x, g23.y);
-                store4(t4, OALSFX_RV_EARLY_LINE, v23.y, v23.x, v01.y, v01.x); // the early line is fed in reverse line order
-                const v2f e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
-                const v2f e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
-                {
-                    v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
-                    scatter2(r01, r23, sx, sy);
-                    store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
-                }
-
-                // ---- late reverb: taps, T60 (feed-forward per lane, feedback on the chain lanes), all-pass ----
-                {
-                    const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
-                    const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
-                    if (lane < 4) {
-                        row(0, lane)[3] = t60_x;
-                        row(2, lane)[3] = t60_o1b;
-                    }
-                    row(0, 0)[4 + lane] = u01.x; row(0, 1)[4 + lane] = u01.y; row(0, 2)[4 + lane] = u23.x; row(0, 3)[4 + lane] = u23.y;
-                }
-                wave_sync();
-                {
-                    const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TL0);
-                    const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TL1);
-                    const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
-                    const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
-                    const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
-                    const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
-                    row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
-                }
-                wave_sync();
-                if (lane < 4) first_order_chain(row(1, lane), row(2, lane), 0, L, utf[ut::TL2 + lane], 1.0F, false, t60_o1);
-                wave_sync();
-                {
-                    const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
-                    const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TH1);
-                    const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
-                    const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
-                    const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
-                    const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
-                    row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
-                }
-                wave_sync();
-                if (lane < 4) {
-                    first_order_chain(row(1, lane), row(1, lane), 0, L, utf[ut::TH2 + lane], utf[ut::TMID + lane], true, t60_o2);
-                    t60_x = row(0, lane)[4 + L - 1];
-                    t60_o1b = t60_o1;
-                }
-                wave_sync();
-                v2f l01, l23;
-                {
-                    const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
-                    const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
-                    l01 = v2f{p_la.x, p_la.y} - (ac * i01);
-                    l23 = v2f{p_la.z, p_la.w} - (ac * i23);
-                    v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
-                    scatter2(q01, q23, sx, sy);
-                    store4(t4, OALSFX_RV_LATE_AP, q01.x, q01.y, q23.x, q23.y);
-                    v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
-                    scatter2(r01, r23, sx, sy);
-                    store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
-                }
-
-                // ---- pan to the outputs (constant gains in this path) ----
-                {
-                    const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
-#pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
-                        const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k); // gains of two lines: L,R,L,R
-                        if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
-                        if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
-                        if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
-                        if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
-                    }
-                }
-                {
-                    if (last) {
-                        if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
-                        else dst[pos] = o0;
-                    } else {
-                        mixbuf[pos] = o0;
-                        if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos] = o1;
-                    }
-                }
-        }
-        mod_index = (mod_index + todo) % mod_range; // the modulator index advances even when its depth is zero
-        offset += todo;
-        base += todo;
-    }
-
-    // ---- hand the state back (to the next launch, or to the general kernel for the rest of this buffer) ----
-    if (lane < 4) {
-        S.lp[lane].x[0] = lpx0; S.lp[lane].x[1] = lpx1;
-        S.lp[lane].y[0] = lpy0; S.lp[lane].y[1] = lpy1;
-        if (eax) {
-            S.hp[lane].x[0] = lpy0; S.hp[lane].x[1] = lpy1;
-            S.hp[lane].y[0] = hpy0; S.hp[lane].y[1] = hpy1;
-        }
-        S.t60[lane][0][0] = t60_x; S.t60[lane][0][1] = t60_o1;
-        S.t60[lane][1][0] = t60_o1b; S.t60[lane][1][1] = t60_o2;
-    }
-    if (lane == 0) {
-        S.mod_index = mod_index;
-        S.offset = offset;
-        ctx.progress[sidx] = base;
-    }
-    if (first && base >= frames && lane < CH) {
-        float* tail = ctx.src_tail + (static_cast<size_t>(inst) * CH + lane) * 2;
-        if (frames >= 2) {
-            tail[0] = src[static_cast<size_t>(frames - 1) * CH + lane];
-            tail[1] = src[static_cast<size_t>(frames - 2) * CH + lane];
-        } else if (frames == 1) {
-            tail[1] = tail[0];
-            tail[0] = src[lane];
-        }
-    }
-}
-
-
-// =================================================================================================
 // Cooperative steady-state kernel: like k_reverb_steady (one wavefront per instance, 64 sample times per
 // tile, packed arithmetic, prefetched taps), but the serial filter recurrences of the four instances of a
 // workgroup are run together: for every chain phase one wavefront executes the recurrences of all 16
@@ -581,6 +196,9 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady(KernelCtx ctx, int slo
 // Barriers are raw s_barrier preceded by s_waitcnt lgkmcnt(0) only: LDS traffic must be complete, global
 // loads (the prefetch of the next tile) and ring stores stay in flight across them.
 // =================================================================================================
+template <int CH>
+__device__ __noinline__ void reverb_general_call(const KernelCtx* ctx, int slot, int inst, int flags, float* lds, int lane);
+
 namespace coop {
 enum { LPX0, LPX1, LPY0, LPY1, HPY0, HPY1, T60X, T60O1, T60O2, LP_A1, LP_A2, HP_A1, HP_A2, T_L2, T_H2, T_MID, SIZE };
 }
@@ -594,7 +212,7 @@ template <int CH, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
-    constexpr int kFloats = kGroups * 4 * kRow + ut::SIZE;
+    constexpr int kFloats = Lds<CH>::kFloats; // sized for the general path, which non-steady instances fall back to below
     __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
     __shared__ float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     __shared__ int go_all[NW];
@@ -649,7 +267,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     }
     if (lane == 0) {
         go_all[wib] = go ? 1 : 0;
-        if (valid && !go) ctx.progress[sidx] = 0;
     }
 
     unsigned aud_dir = 0, aud_aux = 0, aud_out = 0;
@@ -747,13 +364,16 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     float* cdat = chain_all[cw][cc];
 
     lds_barrier(); // tables, chain data and go flags are in place
+    bool any_go = false;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) any_go |= go_all[k] != 0;
     const bool chain_on = (lane < 4 * NW) && go_all[cw] != 0;
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
     // put the same phase on the same SIMD
     const int duty = (wib - static_cast<int>(blockIdx.x)) & (NW - 1);
     if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
 
-    const int tiles = frames >> 6;
+    const int tiles = any_go ? frames >> 6 : 0; // a workgroup without a steady instance skips the cooperative loop altogether
     for (int tile = 0; tile < tiles; ++tile) {
         const int pos = (tile << 6) + lane;
         const unsigned t4 = static_cast<unsigned>(offset + pos) << 2;
@@ -955,7 +575,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         if (lane == 0) {
             S.mod_index = static_cast<int>((static_cast<long long>(S.mod_index) + frames) % S.mod_range);
             S.offset = offset + frames;
-            ctx.progress[sidx] = frames;
         }
         if (first && lane < CH) {
             float* tail = ctx.src_tail + (static_cast<size_t>(inst) * CH + lane) * 2;
@@ -963,27 +582,30 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             tail[1] = src[static_cast<size_t>(frames - 2) * CH + lane];
         }
     }
+    // ---- instances that are not in their steady state ----
+    if (flags & kDeferGeneral) {
+        // a general kernel follows on the same list: tell it how far this instance got
+        if (valid && lane == 0) ctx.progress[sidx] = go ? frames : 0;
+    } else if (valid && !go) {
+        // no second launch was planned (the host expected every instance to be steady): the general path, out of line
+        KernelCtx whole = ctx;
+        whole.progress = nullptr; // nothing of this buffer has been processed for this instance
+        reverb_general_call<CH>(&whole, slot, inst, flags & 0xFF, lds, lane);
+    }
 }
 
+// General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
+// partial tiles, any channel count.  Starts at the frame recorded in ctx.progress by a steady-state kernel (if one ran).
 template <int CH>
-__global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, int slot, int inst, int flags, float* lds, int lane)
 {
     constexpr int NQ = Lds<CH>::kChains;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];
-
-    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * 4 + wave_in_block;
-    if (w >= count) return;
-    const int lane = threadIdx.x & 63;
-
-    float* lds = lds_all[wave_in_block];
     auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
     float* rng = lds + kGroups * 4 * kRow;
     float* gseq = rng + kRngFloats;
     float* utf = gseq + NQ * 64;                             // uniform table, float view
     unsigned* utu = reinterpret_cast<unsigned*>(utf);        // ... unsigned view
 
-    const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
@@ -1528,33 +1150,62 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     }
 }
 
-void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)
+
+// Out-of-line entry used by the steady-state kernel for the instances it cannot take: keeps the general path's
+// register footprint out of the steady-state tile loop.
+template <int CH>
+__device__ __noinline__ void reverb_general_call(const KernelCtx* ctx, int slot, int inst, int flags, float* lds, int lane)
+{
+    reverb_general_instance<CH>(*ctx, slot, inst, flags, lds, lane);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+{
+    __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    // grid-stride over the list: launched with one wavefront per instance when work is expected, and with a small grid
+    // (each wavefront checks several instances' progress markers) when the host believes every instance is steady
+    const int stride = static_cast<int>(gridDim.x) * 4;
+    const int wave_id = blockIdx.x * 4 + wave_in_block;
+    for (int w0 = wave_id; w0 < count; w0 += 64 * stride) {
+        // lane k looks at the k-th instance of this wavefront's share: all progress markers are fetched in one go
+        const int wk = w0 + lane * stride;
+        bool need = false;
+        int inst_k = 0;
+        if (wk < count) {
+            inst_k = list[wk];
+            need = ctx.progress == nullptr || ctx.progress[static_cast<size_t>(inst_k) * ctx.slots + slot] < ctx.frames;
+        }
+        unsigned long long todo_mask = __ballot(need);
+        while (todo_mask != 0ULL) {
+            const int k = __builtin_ctzll(todo_mask);
+            todo_mask &= todo_mask - 1ULL;
+            const int inst = __shfl(inst_k, k);
+            reverb_general_instance<CH>(ctx, slot, __builtin_amdgcn_readfirstlane(inst), flags, lds_all[wave_in_block], lane);
+            wave_sync();
+        }
+    }
+}
+
+void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream)
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    const int dbg = flags >> 8; // timing experiments only: 8 = no steady-state kernel, 16 = per-wave (non-cooperative) steady kernel
-    const bool steady_first = ctx.progress != nullptr && ctx.channels <= 2 && !(dbg & 8);
-    if (steady_first) {
-        if (dbg & 16) {
-            if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb_steady<1>, grid, block, 0, stream, ctx, slot, list, count, flags);
-            else hipLaunchKernelGGL(k_reverb_steady<2>, grid, block, 0, stream, ctx, slot, list, count, flags);
-        } else {
-            if (dbg & 64) {
-                const dim3 grid2((count + 1) / 2), block2(128);
-                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 2>), grid2, block2, 0, stream, ctx, slot, list, count, flags);
-                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 2>), grid2, block2, 0, stream, ctx, slot, list, count, flags);
-            } else if (dbg & 32) {
-                const dim3 grid8((count + 7) / 8), block8(512);
-                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 8>), grid8, block8, 0, stream, ctx, slot, list, count, flags);
-                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 8>), grid8, block8, 0, stream, ctx, slot, list, count, flags);
-            } else {
-                if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, ctx, slot, list, count, flags);
-                else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, ctx, slot, list, count, flags);
-            }
-        }
-    }
+    const int dbg = flags >> 8; // timing experiments only: 8 = general kernel only
     KernelCtx general = ctx;
-    if (!steady_first) general.progress = nullptr;
+    if (ctx.channels <= 2 && !(dbg & 8)) {
+        // Steady-state instances run the cooperative tile loop.  If the host expects all of them to be steady this is the
+        // only launch (an instance that turns out not to be falls back to the general path inside it, out of line);
+        // otherwise the others are deferred to the general kernel below, which runs them at full occupancy.
+        const int f = flags | (expect_steady ? 0 : kDeferGeneral);
+        if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
+        else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
+        if (expect_steady) return;
+    } else {
+        general.progress = nullptr;
+    }
     if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, general, slot, list, count, flags);
     else if (ctx.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, general, slot, list, count, flags);
     else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, general, slot, list, count, flags);

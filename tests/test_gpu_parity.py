@@ -156,3 +156,25 @@ def test_cpp_api_dropin(tmp_path):
     want = np.concatenate([api.mix(orc.synth(77, k, n * 2).reshape(n, 2)).reshape(-1) for k, n in enumerate((256, 256, 256, 100, 3000))])
     ok, nbad = same_bits(got, want)
     assert ok, f"{nbad} of {want.size} samples differ"
+
+
+def test_eax_modulation_switched_off_midstream():
+    """After modulation is switched off the depth smoother keeps decaying for a long time: the host believes the
+    instance is steady again after one buffer, the device knows better and takes the in-kernel fallback."""
+    mod = E(desc.EAX_REVERB, modulation_depth=1.0, modulation_time=0.5)
+    plain = E(desc.EAX_REVERB, modulation_depth=0.0, modulation_time=0.5)
+    script = [("mix", 256)] * 3 + [("set", 0, 0, plain), ("set", 2, 0, plain), ("apply",)] + [("mix", 256)] * 6
+    run_batch(desc.FMT_STEREO, 48000, 1, [[(0, mod)], [(0, E(desc.EAX_REVERB))], [(0, mod)], [(0, preset_effect(5))], [(0, E(desc.EAX_REVERB))]], script)
+
+
+def test_large_batch_mixed_steady_and_transitional():
+    """Enough instances for several workgroups, a third of them permanently on the general path (modulated / dense presets)."""
+    setups = []
+    for i in range(37):
+        if i % 3 == 0:
+            setups.append([(0, E(desc.EAX_REVERB, modulation_depth=0.7, density=0.1))])
+        elif i % 3 == 1:
+            setups.append([(0, E(desc.EAX_REVERB))])
+        else:
+            setups.append([(0, preset_effect(i % 113))])
+    run_batch(desc.FMT_STEREO, 48000, 1, setups, [("mix", 256)] * 5 + [("mix", 64), ("mix", 192), ("mix", 100), ("mix", 256)])
