@@ -179,7 +179,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": "k_reverb<2>",
+            "kernel": "k_reverb_steady_coop<2,4>" if not args.preset_mix else "k_reverb_steady_coop<2,4> + k_reverb<2>",
             "kernel_us": round(avg_kernel_s * 1e6, 2),
             "launches_timed": launches,
             "algorithmic_bytes_per_launch": BYTES_PER_FRAME * frames_per_launch,

@@ -96,6 +96,11 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
 
+/* ---- measurement helper: sweeps a scratch buffer of `bytes` with the reverb kernel's access shape (one dword per lane,
+ * 256 contiguous bytes per wave instruction), `repeats` launches of k_hbm_sweep, reading (write == 0) or writing.  Used under
+ * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE to calibrate those counters against a known byte count (profiles/README.md). */
+int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats);
+
 /* ---- host-only helpers (no GPU needed): the parameter-update path, exposed so the descriptors can be
  * checked against the reference and so the CPU oracle can be driven with identical parameters. */
 void oalsfx_host_effect_defaults(int effect_type, oalsfx_effect* out);        /* Effect::set_type_and_defaults */

@@ -672,4 +672,19 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     return 1;
 }
 
+int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats)
+{
+    if (hipSetDevice(device_id) != hipSuccess) return 0;
+    float* buf = nullptr;
+    float* sink = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&buf), bytes) != hipSuccess) return 0;
+    if (hipMalloc(reinterpret_cast<void**>(&sink), 256) != hipSuccess) { (void)hipFree(buf); return 0; }
+    (void)hipMemset(buf, 0, bytes);
+    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_hbm_sweep(buf, bytes / sizeof(float), write, sink, nullptr);
+    const bool ok = hipDeviceSynchronize() == hipSuccess;
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    return ok ? 1 : 0;
+}
+
 } // extern "C"

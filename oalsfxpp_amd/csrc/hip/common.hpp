@@ -45,6 +45,7 @@ constexpr int kWave = 64;
 void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream);
 void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
+void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 
 #if defined(__HIPCC__)
 

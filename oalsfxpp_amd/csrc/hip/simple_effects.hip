@@ -387,4 +387,23 @@ void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, u
     hipLaunchKernelGGL(k_fill_synthetic, dim3((instances + 63) / 64), dim3(64), 0, stream, dst, instances, floats_per_instance, buffer_index);
 }
 
+// ---- HBM counter calibration (measurement helper): reads or writes a buffer with the access shape of the reverb
+// kernel's ring traffic: one dword per lane, 256 contiguous bytes per wave instruction.  Run under
+// rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE it gives the factor between counter values and real bytes for this shape.
+__global__ void k_hbm_sweep(float* buf, size_t floats, int write, float* sink)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    float acc = 0.0F;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < floats; i += stride) {
+        if (write) buf[i] = static_cast<float>(i & 1023);
+        else acc += buf[i];
+    }
+    if (!write && acc == 12345.678F) sink[0] = acc; // keeps the loads alive
+}
+
+void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_hbm_sweep, dim3(256 * 8), dim3(256), 0, stream, buf, floats, write, sink);
+}
+
 } // namespace oalsfx_hip
