@@ -31,6 +31,20 @@ CHANNELS = 2
 BYTES_PER_FRAME = 208          # 16 B I/O + 24 fp32 delay-line reads + 24 fp32 delay-line writes
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 METRIC = "Msamples/sec EAX reverb, 256-frame buffers, batch=4096; % HBM roofline"
+METRICS = {
+    "config3": "Msamples/sec 4-slot chain (chorus, flanger, echo, EAX reverb), 256-frame buffers, batch=4096; % HBM roofline",
+    "config4": "Msamples/sec 11 effect types mixed, randomised properties, 256-frame buffers, batch=8192; % HBM roofline",
+}
+WORKLOADS = {
+    "config2": "{n} independent EAX-reverb instances per GPU, stereo, 48 kHz, 256-frame buffers, 1 slot, default properties "
+               "(BASELINE.json configs[1])",
+    "config2-presets": "{n} independent EAX-reverb instances per GPU, stereo, 48 kHz, 256-frame buffers, 1 slot, "
+                       "EFX preset i%113 per instance (BASELINE.json configs[1], robustness run)",
+    "config3": "{n} instances per GPU x 4 parallel slots (chorus, flanger, echo, EAX reverb; defaults), stereo, 48 kHz, "
+               "256-frame buffers (BASELINE.json configs[2])",
+    "config4": "{n} instances per GPU, 1 slot, effect type 1 + i%11, every property uniform in its range (seed = instance), "
+               "stereo, 48 kHz, 256-frame buffers (BASELINE.json configs[3])",
+}
 
 
 def usable_cores():
@@ -81,15 +95,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--instances", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default 4096; 8192 for config4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"],
+                    help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain) or configs[3] "
+                         "(11 effect types, randomised properties; 8192 instances unless --instances is given)")
+    ap.add_argument("--host-io", type=int, default=0, metavar="K",
+                    help="after the timed region, also time K steps through oalsfx_batch_mix (host buffers, PCIe both ways)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    from oalsfxpp_amd import desc, lib, sharding
+    from oalsfxpp_amd import desc, lib, sharding, workloads
     from oalsfxpp_amd.api import Batch
 
     rank, world, local_rank = sharding.env_rank_world()
@@ -100,18 +119,10 @@ def main():
     if distributed:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    n = args.instances
-    batch = Batch(n, desc.FMT_STEREO, 48000, 1, device_id=local_rank)
-    if args.preset_mix:
-        effects = []
-        for i in range(n):
-            e = lib.effect_defaults(desc.EAX_REVERB)
-            e.props.reverb = lib.preset(i % lib.preset_count())[1]
-            effects.append(e)
-        batch.set_effect(0, effects)
-    else:
-        batch.set_effect_type(0, desc.EAX_REVERB)
-    batch.apply_changes()
+    n = args.instances or (8192 if args.workload == "config4" else 4096)
+    workload = "config2-presets" if args.preset_mix else args.workload
+    batch = Batch(n, desc.FMT_STEREO, 48000, workloads.effect_count(workload), device_id=local_rank)
+    workloads.setup(batch, workload, first_instance=rank * n)
 
     # inputs resident in HBM: a ring of pre-generated buffers, one output buffer
     n_in = 8
@@ -144,15 +155,33 @@ def main():
     torch.cuda.synchronize()
     elapsed = sharding.max_over_ranks(elapsed, device="cuda")
 
-    launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
+    # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
+    kernels = {}
+    for t in range(1, 12):
+        l, ms = batch.kernel_timing_read(t)
+        if l:
+            kernels[desc.EFFECT_NAMES[t]] = {"launches": l, "avg_us": round(ms / l * 1e3, 2)}
+    frames_per_launch = n * FRAMES
+    if workload == "config3":
+        bytes_per_step = workloads.CONFIG3_BYTES_PER_FRAME * frames_per_launch
+    elif workload == "config4":
+        bytes_per_step = sum(workloads.BYTES_PER_FRAME[workloads.config4_type(rank * n + i)] for i in range(n)) * FRAMES
+    else:
+        bytes_per_step = BYTES_PER_FRAME * frames_per_launch
+    if workload.startswith("config2"):
+        # the headline: the dominant kernel alone
+        launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
+    else:
+        # several kernels share a step: all of them against all of the step's algorithmic bytes
+        launches = args.steps
+        kernel_ms = sum(batch.kernel_timing_read(t)[1] for t in range(12))
     batch.kernel_timing(False)
     avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-    frames_per_launch = n * FRAMES
-    achieved_gbs = BYTES_PER_FRAME * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    achieved_gbs = bytes_per_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
     total_frames = world * n * FRAMES * args.steps
     result = {
-        "metric": METRIC,
+        "metric": METRIC if workload.startswith("config2") else METRICS[workload],
         "value": round(total_frames / elapsed / 1e6, 3),
         "unit": "Msamples/s",
         "n_gpus": world,
@@ -165,9 +194,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{n} independent EAX-reverb instances per GPU, stereo, 48 kHz, 256-frame buffers, 1 slot, "
-                        + ("EFX preset i%113 per instance" if args.preset_mix else "default properties")
-                        + " (BASELINE.json configs[1])",
+            "workload": WORKLOADS[workload].format(n=n),
             "instances_per_gpu": n,
             "frames_per_buffer": FRAMES,
             "parallelism": f"batch-split x{world}, no collectives",
@@ -179,18 +206,38 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": "k_reverb_steady_coop<2,4>" if not args.preset_mix else "k_reverb_steady_coop<2,4> + k_reverb<2>",
+            "kernel": {"config2": "k_reverb_steady_coop<2,4>", "config2-presets": "k_reverb_steady_coop<2,4> + k_reverb<2>"}.get(
+                workload, "all effect kernels of a step"),
             "kernel_us": round(avg_kernel_s * 1e6, 2),
             "launches_timed": launches,
-            "algorithmic_bytes_per_launch": BYTES_PER_FRAME * frames_per_launch,
+            "algorithmic_bytes_per_launch": bytes_per_step,
         },
+        "kernels": kernels,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and not args.preset_mix and n == 4096:
+    if os.path.exists(traffic_file) and workload == "config2" and n == 4096:
         with open(traffic_file) as f:
             t = json.load(f)
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = t.get("source")
+
+    if args.host_io > 0:
+        # PCIe-inclusive rate (never `value`): pinned host buffers through oalsfx_batch_mix, synchronous per step
+        hsrc = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).uniform_(-1, 1).pin_memory()
+        hdst = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).pin_memory()
+        import ctypes as C
+        fp = C.POINTER(C.c_float)
+        so = lib.load()
+        call = lambda: so.oalsfx_batch_mix(batch._h, FRAMES, C.cast(hsrc.data_ptr(), fp), C.cast(hdst.data_ptr(), fp))
+        for _ in range(3):
+            assert call()
+        t0 = time.perf_counter()
+        for _ in range(args.host_io):
+            assert call()
+        dt = time.perf_counter() - t0
+        result["host_io"] = {"value": round(n * FRAMES * args.host_io / dt / 1e6, 3), "unit": "Msamples/s",
+                             "ms_per_step": round(dt / args.host_io * 1e3, 4), "steps": args.host_io,
+                             "note": "pinned host src/dst, H2D + kernels + D2H + sync per step, not overlapped"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -31,9 +31,6 @@ namespace {
 
 thread_local std::string g_last_error;
 
-const char* const kErrNotSupportedFilters =
-    "Send filters (gain_hf / gain_lf != 1) are not implemented on the GPU path yet.";
-
 struct RingPool {
     size_t slab_floats = 0;
     std::vector<float*> free_clean; // zero-filled, never used since allocation
@@ -69,7 +66,9 @@ struct oalsfx_batch {
     oalsfx_slot_state* d_state = nullptr;
     oalsfx_source_params* d_source = nullptr;
     float** d_rings = nullptr;
-    float* d_tail = nullptr;
+    oalsfx_source_state* d_source_state = nullptr; // [n] histories of the send filters
+    float* d_filtered = nullptr;                  // [1 + slots][n][chunk frames][channels] outputs of the send-filter pre-pass
+    size_t filtered_capacity = 0;                 // floats per send plane
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
     int* d_progress = nullptr;                    // [n*slots] hand-off between the steady-state and the general reverb kernel
@@ -237,7 +236,7 @@ bool sync_params(oalsfx_batch* b)
     }
     b->dirty_list.clear();
 
-    // send filters: only the pass-through path exists on the GPU so far
+    // send filters: while any instance has one switched on, every mix starts with the filter pre-pass
     b->filters_active = false;
     for (int i = 0; i < b->n && !b->filters_active; ++i) {
         if (b->h_source[i].direct.filter_type != OALSFX_AF_NONE) b->filters_active = true;
@@ -328,7 +327,7 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
 {
     const int count = b->list_count[slot][type];
     if (count == 0) return;
-    if (type == OALSFX_NULL && flags == 0) return; // a null effect in the middle of the chain does nothing
+    if (type == OALSFX_NULL && (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) == 0) return; // a null effect in the middle of the chain does nothing
     const int* list = b->d_lists + b->list_offset[slot][type];
     TimedLaunch tl{};
     if (b->timing) {
@@ -352,14 +351,24 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
 {
     if (!sync_params(b)) return false;
-    if (b->filters_active) return b->fail(kErrNotSupportedFilters);
     if (!ensure_mixbuf(b)) return false;
+    const bool filtered = b->filters_active;
+    const int chunk_max = std::min(frames, OALSFX_MAX_CHUNK);
+    const size_t plane = static_cast<size_t>(b->n) * chunk_max * b->channels;
+    if (filtered && plane > b->filtered_capacity) {
+        if (!b->hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+        hipFree(b->d_filtered);
+        b->d_filtered = nullptr;
+        b->filtered_capacity = 0;
+        if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_filtered), plane * (1 + b->slots) * sizeof(float)), "hipMalloc(filtered sends)")) return false;
+        b->filtered_capacity = plane;
+    }
     KernelCtx ctx{};
     ctx.params = b->d_params;
     ctx.state = b->d_state;
     ctx.rings = b->d_rings;
     ctx.source = b->d_source;
-    ctx.src_tail = b->d_tail;
+    ctx.source_state = b->d_source_state;
     ctx.mixbuf = b->d_mixbuf;
     ctx.progress = b->d_progress;
     ctx.slots = b->slots;
@@ -368,11 +377,22 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     // Api::mix chunking (reference src/oalsfxpp.cpp:3818-3826)
     for (int done = 0; done < frames;) {
         const int n = std::min(frames - done, OALSFX_MAX_CHUNK);
-        ctx.src = src + static_cast<size_t>(done) * b->channels;
+        const float* chunk_src = src + static_cast<size_t>(done) * b->channels;
         ctx.dst = dst + static_cast<size_t>(done) * b->channels;
         ctx.frames = n;
+        if (filtered) {
+            // apply_filters for every send (reference src/oalsfxpp.cpp:2929-2965): planes of [instance][n][channels]
+            ctx.src_stride = static_cast<long long>(n) * b->channels;
+            oalsfx_hip::launch_send_filters(ctx, chunk_src, ctx.io_stride, b->d_filtered, b->filtered_capacity, b->n, stream);
+            ctx.src = b->d_filtered;
+        } else {
+            ctx.src_stride = ctx.io_stride;
+            ctx.src = chunk_src;
+        }
         for (int s = 0; s < b->slots; ++s) {
-            const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0);
+            const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0) |
+                              (filtered ? oalsfx_hip::kFiltered : 0);
+            ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
             for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) launch_type(b, t, ctx, s, flags, stream);
         }
         done += n;
@@ -440,12 +460,12 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_slot_state)), "hipMalloc(state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_tail), static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float)), "hipMalloc(tail)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
-    ok = ok && b->hip_ok(hipMemsetAsync(b->d_tail, 0, static_cast<size_t>(n_instances) * b->channels * 2 * sizeof(float), b->stream), "hipMemsetAsync(tail)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
     if (!ok) {
         g_last_error = b->error;
         oalsfx_batch_destroy(b);
@@ -461,7 +481,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     if (b->stream) hipStreamSynchronize(b->stream);
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (void* c : b->chunks) hipFree(c);
-    hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_tail);
+    hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
@@ -621,20 +641,8 @@ int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params
     if (!sync_params(b)) return 0;
     if (params) *params = b->h_source[instance];
     if (state) {
-        // pass-through sends keep the last two input samples on both sides of every filter
-        // (reference process_pass_through, src/oalsfxpp.cpp:1038-1056)
-        std::memset(state, 0, sizeof(*state));
-        float tail[OALSFX_MAX_CHANNELS][2];
-        hipStreamSynchronize(b->stream);
-        if (!b->hip_ok(hipMemcpy(tail, b->d_tail + static_cast<size_t>(instance) * b->channels * 2, sizeof(float) * 2 * b->channels, hipMemcpyDeviceToHost), "hipMemcpy(tail)")) return 0;
-        for (int send = 0; send <= b->slots; ++send) {
-            if (send > 0 && b->h_source[instance].aux[send - 1].out_channels == 0) continue; // null slot: send disabled
-            for (int c = 0; c < b->channels; ++c)
-                for (int k = 0; k < 2; ++k) {
-                    state->lp[send][c].x[k] = state->lp[send][c].y[k] = tail[c][k];
-                    state->hp[send][c].x[k] = state->hp[send][c].y[k] = tail[c][k];
-                }
-        }
+        if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+        if (!b->hip_ok(hipMemcpy(state, b->d_source_state + instance, sizeof(*state), hipMemcpyDeviceToHost), "hipMemcpy(source state)")) return 0;
     }
     return 1;
 }

@@ -19,15 +19,17 @@ struct KernelCtx {
     oalsfx_slot_state* state;           // [instance][slots]
     float* const* rings;                // [instance][slots] -> ring slab of that slot (or nullptr)
     const oalsfx_source_params* source; // [instance]
-    float* src_tail;                    // [instance][channels][2]: last two input frames (newest first)
-    const float* src;                   // [instance][frames][channels] interleaved input of this chunk
+    oalsfx_source_state* source_state;  // [instance]: histories of the send filters
+    const float* src;                   // [instance][frames][channels] interleaved input of this chunk as the direct send sees it
+    const float* wet_src;               // ... as this slot's auxiliary send sees it (== src unless kFiltered)
     float* dst;                         // [instance][frames][channels] interleaved output of this chunk
     float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
     int* progress;                      // [instance][slots]: frames of this chunk already done by a steady-state kernel
     int slots;
     int channels;
     int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
-    long long io_stride;                // floats between consecutive instances in src / dst
+    long long io_stride;                // floats between consecutive instances in dst
+    long long src_stride;               // floats between consecutive instances in src / wet_src
 };
 
 // Flags of one launch: which duties of the mix loop this slot's kernel performs.
@@ -36,6 +38,8 @@ enum : int {
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
     kEax = 4,   // reverb kernels: the list holds EAX reverb instances (second input shelf active)
     kDeferGeneral = 8, // steady-state reverb kernel: leave non-steady instances to the general kernel launched next
+    kFiltered = 16, // the send filters ran as a pre-pass (k_send_filters): src / wet_src are its outputs and the filter
+                    // histories are already up to date
 };
 
 constexpr int kWave = 64;
@@ -44,6 +48,10 @@ constexpr int kWave = 64;
 // expect_steady: host-side belief that every listed instance is in its steady state (speed hint only)
 void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream);
 void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+// Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
+// send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
+void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
+                         hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
 void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 
@@ -112,6 +120,31 @@ __device__ __forceinline__ float biquad_step(const oalsfx_biquad_t& c, oalsfx_hi
     h.y[1] = h.y[0];
     h.y[0] = y;
     return y;
+}
+
+// Pass-through sends (ActiveFilters::none): the histories of both shelf filters of every enabled send follow the input
+// (reference process_pass_through, src/oalsfxpp.cpp:1038-1056; disabled sends of null slots are skipped, :2952-2956).
+// Called for input channel c by the kernel that owns the kFirst duty when no filter pre-pass ran.
+__device__ __forceinline__ void send_history_follow(const KernelCtx& ctx, int inst, int c, int channels, int frames, const float* src)
+{
+    if (frames <= 0) return;
+    const oalsfx_source_params& P = ctx.source[inst];
+    oalsfx_source_state& S = ctx.source_state[inst];
+    const float newest = src[static_cast<size_t>(frames - 1) * channels + c];
+    const float older = frames >= 2 ? src[static_cast<size_t>(frames - 2) * channels + c] : 0.0F;
+    for (int send = 0; send <= ctx.slots; ++send) {
+        if (send > 0 && P.aux[send - 1].out_channels == 0) continue;
+        oalsfx_hist_t* h[2] = {&S.lp[send][c], &S.hp[send][c]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (frames >= 2) {
+                h[k]->x[1] = older; h[k]->y[1] = older;
+            } else {
+                h[k]->x[1] = h[k]->x[0]; h[k]->y[1] = h[k]->y[0];
+            }
+            h[k]->x[0] = newest; h[k]->y[0] = newest;
+        }
+    }
 }
 
 // Synthetic benchmark input, identical to oracle_synth.

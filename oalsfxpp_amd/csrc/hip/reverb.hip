@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
 
     // ---- is this instance in its steady state for the whole buffer? (see k_reverb_steady) ----
-    bool go = valid && (frames & 63) == 0 && (SS.seen_seq == SP.update_seq) && (S.fade_count >= OALSFX_RV_FADE_SAMPLES) &&
+    bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (SS.seen_seq == SP.update_seq) && (S.fade_count >= OALSFX_RV_FADE_SAMPLES) &&
               (P.mod_depth == 0.0F) && (S.mod_filter == 0.0F);
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
     const bool q_valid = lane < 8 * CH;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 
     unsigned aud_dir = 0, aud_aux = 0, aud_out = 0;
     int offset = 0;
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
+    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * CH * OALSFX_MAX_CHUNK : nullptr;
     const float b2a = 0.288675134595F;
@@ -576,11 +576,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             S.mod_index = static_cast<int>((static_cast<long long>(S.mod_index) + frames) % S.mod_range);
             S.offset = offset + frames;
         }
-        if (first && lane < CH) {
-            float* tail = ctx.src_tail + (static_cast<size_t>(inst) * CH + lane) * 2;
-            tail[0] = src[static_cast<size_t>(frames - 1) * CH + lane];
-            tail[1] = src[static_cast<size_t>(frames - 2) * CH + lane];
-        }
+        if (first && lane < CH) send_history_follow(ctx, inst, lane, CH, frames, src);
     }
     // ---- instances that are not in their steady state ----
     if (flags & kDeferGeneral) {
@@ -715,7 +711,9 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
     }
 
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
+    const bool filtered = (flags & kFiltered) != 0;
+    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
 
@@ -789,7 +787,8 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
             wave_sync(); // ring stores of the previous tile precede the loads below (program order)
 
             // ---------------- loads that do not depend on this tile ----------------
-            float in[CH];
+            float in[CH];   // the frame as the direct send sees it
+            float win[CH];  // ... as this slot's auxiliary send sees it (differs only after the send-filter pre-pass)
             float out[CH];
 #pragma unroll
             for (int c = 0; c < CH; ++c) { in[c] = 0.0F; out[c] = 0.0F; }
@@ -802,6 +801,13 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     for (int c = 0; c < CH; ++c)
                         if (c < channels) in[c] = src[static_cast<size_t>(pos) * channels + c];
                 }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) win[c] = in[c];
+            if (filtered && act) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < channels) win[c] = wsrc[static_cast<size_t>(pos) * channels + c];
             }
             float p_e[4], p_a[4], p_el[4], p_lt[4], p_ll[4], p_la[4];
 #pragma unroll
@@ -837,7 +843,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float g = SRC.aux[slot].gains[c][k];
-                    if (audible(g)) wet[k] += in[c] * g;
+                    if (audible(g)) wet[k] += win[c] * g;
                 }
             }
             float a[4];
@@ -1137,17 +1143,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         S.fade_count = fade_count; S.offset = offset;
         SS.seen_seq = SP.update_seq;
     }
-    if (first && lane < channels) {
-        // last two input frames of the stream (pass-through history of the send filters)
-        float* tail = ctx.src_tail + (static_cast<size_t>(inst) * channels + lane) * 2;
-        if (frames >= 2) {
-            tail[0] = src[static_cast<size_t>(frames - 1) * channels + lane];
-            tail[1] = src[static_cast<size_t>(frames - 2) * channels + lane];
-        } else if (frames == 1) {
-            tail[1] = tail[0];
-            tail[0] = src[lane];
-        }
-    }
+    if (first && !filtered && lane < channels) send_history_follow(ctx, inst, lane, channels, frames, src);
 }
 
 

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(64) void k_simple(KernelCtx ctx, int slot, const in
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
 
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.io_stride;
+    const bool filtered = (flags & kFiltered) != 0;
+    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
 
@@ -284,10 +286,11 @@ __global__ __launch_bounds__(64) void k_simple(KernelCtx ctx, int slot, const in
     fx.init(SP, SS, ctx.rings[sidx]);
 
     for (int i = 0; i < frames; ++i) {
-        float in[CH], out[CH];
+        float in[CH], win[CH], out[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             in[c] = (c < channels) ? src[static_cast<size_t>(i) * channels + c] : 0.0F;
+            win[c] = (filtered && c < channels) ? wsrc[static_cast<size_t>(i) * channels + c] : in[c];
             out[c] = 0.0F;
         }
         float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(64) void k_simple(KernelCtx ctx, int slot, const in
             if (send_on) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (audible(aux_gain[c][k])) wet[k] += in[c] * aux_gain[c][k];
+                    if (audible(aux_gain[c][k])) wet[k] += win[c] * aux_gain[c][k];
             }
         }
         if (!first) {
@@ -327,18 +330,61 @@ __global__ __launch_bounds__(64) void k_simple(KernelCtx ctx, int slot, const in
     fx.finish(SS);
     SS.seen_seq = SP.update_seq;
 
-    if (first) {
-        for (int c = 0; c < channels; ++c) {
-            float* tail = ctx.src_tail + (static_cast<size_t>(inst) * channels + c) * 2;
-            if (frames >= 2) {
-                tail[0] = src[static_cast<size_t>(frames - 1) * channels + c];
-                tail[1] = src[static_cast<size_t>(frames - 2) * channels + c];
-            } else if (frames == 1) {
-                tail[1] = tail[0];
-                tail[0] = src[c];
-            }
+    if (first && !filtered)
+        for (int c = 0; c < channels; ++c) send_history_follow(ctx, inst, c, channels, frames, src);
+}
+
+// Send shelf filters as a pre-pass (reference apply_filters, src/oalsfxpp.cpp:3101-3143, called from mix_source :2929-2965).
+// One wavefront per instance; lane = send * 8 + input channel runs that send's two biquads over the chunk in sample order,
+// so the recurrences round like the reference's.  Sends without a filter copy their input, which lets the effect kernels
+// read every send from the same place.  Runs only while some instance of the batch has a filter switched on.
+__global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float* __restrict__ src_all, long long src_stride,
+                                                      float* __restrict__ filtered, size_t send_floats, int instances)
+{
+    const int lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (inst >= instances) return;
+    const int channels = ctx.channels;
+    const int send = lane >> 3;
+    const int c = lane & 7;
+    if (send > ctx.slots || c >= channels) return;
+    const oalsfx_source_params& P = ctx.source[inst];
+    const oalsfx_send_params& sp = send == 0 ? P.direct : P.aux[send - 1];
+    if (send > 0 && sp.out_channels == 0) return; // null slot: the send is disabled and its history frozen
+    oalsfx_source_state& S = ctx.source_state[inst];
+    oalsfx_hist_t lp = S.lp[send][c];
+    oalsfx_hist_t hp = S.hp[send][c];
+    const oalsfx_biquad_t clp = sp.lp, chp = sp.hp;
+    const int type = sp.filter_type;
+    const float* src = src_all + static_cast<size_t>(inst) * src_stride + c;
+    float* out = filtered + static_cast<size_t>(send) * send_floats + static_cast<size_t>(inst) * ctx.src_stride + c;
+    const int frames = ctx.frames;
+    for (int base = 0; base < frames; base += 8) {
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (base + k < frames) ? src[static_cast<size_t>(base + k) * channels] : 0.0F;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (base + k >= frames) break;
+            float y = x[k];
+            if (type & OALSFX_AF_LOW_PASS) y = biquad_step(clp, lp, y);
+            else { lp.x[1] = lp.x[0]; lp.x[0] = y; lp.y[1] = lp.y[0]; lp.y[0] = y; }
+            if (type & OALSFX_AF_HIGH_PASS) {
+                // with only the second filter on, it sees the raw input and the first follows the raw input too
+                y = biquad_step(chp, hp, y);
+            } else { hp.x[1] = hp.x[0]; hp.x[0] = y; hp.y[1] = hp.y[0]; hp.y[0] = y; }
+            out[static_cast<size_t>(base + k) * channels] = y;
         }
     }
+    S.lp[send][c] = lp;
+    S.hp[send][c] = hp;
+}
+
+void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
+                         hipStream_t stream)
+{
+    if (instances <= 0 || ctx.frames <= 0) return;
+    hipLaunchKernelGGL(k_send_filters, dim3((instances + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, instances);
 }
 
 template <class Fx>

@@ -17,22 +17,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oalsfxpp_amd import desc, lib  # noqa: E402
+from oalsfxpp_amd.workloads import make_effect  # noqa: E402,F401
 from oracle import oracle as orc  # noqa: E402
-
-
-def make_effect(effect_type, **fields):
-    """Default properties of `effect_type` with some fields overridden (un-normalised)."""
-    e = lib.effect_defaults(effect_type)
-    if fields:
-        member = getattr(e.props, desc.PROPS_MEMBER[effect_type])
-        for k, v in fields.items():
-            if isinstance(v, (list, tuple)):
-                arr = getattr(member, k)
-                for i, x in enumerate(v):
-                    arr[i] = x
-            else:
-                setattr(member, k, v)
-    return e
 
 
 def preset_effect(index, effect_type=desc.EAX_REVERB):
@@ -198,4 +184,6 @@ class OracleShadow:
             ok, nbad = same_bits(ring_gpu, ring_cpu)
             if not ok:
                 diffs.append(f"slot{s}.ring: {nbad} words differ (sizes {ring_gpu.size}/{ring_cpu.size})")
+        _, sst = self.batch.read_source(self.instance)
+        diffs += struct_diff(sst, self.oracle.source_state(), "source_state")
         return diffs

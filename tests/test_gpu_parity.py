@@ -17,7 +17,8 @@ E = make_effect
 
 
 def run_batch(fmt, rate, slots, setups, script, check_instances=None):
-    """setups: per instance, list of (slot, effect).  script: list of ('mix', frames) / ('set', inst, slot, effect) / ('apply',)"""
+    """setups: per instance, list of (slot, effect).  script: list of ('mix', frames) / ('set', inst, slot, effect) /
+    ('send', inst, slot or -1, gain, gain_hf, gain_lf) / ('apply',)"""
     n = len(setups)
     with Batch(n, fmt, rate, slots) as b:
         for i, eff in enumerate(setups):
@@ -30,6 +31,8 @@ def run_batch(fmt, rate, slots, setups, script, check_instances=None):
         for op in script:
             if op[0] == "set":
                 b.set_effect(op[2], op[3], first=op[1], count=1)
+            elif op[0] == "send":
+                b.set_send_props(op[2], op[3], op[4], op[5], first=op[1], count=1)
             elif op[0] == "apply":
                 b.apply_changes()
             else:
@@ -178,3 +181,31 @@ def test_large_batch_mixed_steady_and_transitional():
         else:
             setups.append([(0, preset_effect(i % 113))])
     run_batch(desc.FMT_STEREO, 48000, 1, setups, [("mix", 256)] * 5 + [("mix", 64), ("mix", 192), ("mix", 100), ("mix", 256)])
+
+
+def test_send_filters_all_combinations():
+    """Send shelf filters (apply_filters, reference src/oalsfxpp.cpp:3101-3143): none / high-shelf / low-shelf / both on the
+    direct and the auxiliary sends, switched on and off mid-stream, with 1-frame, odd and > 2048-frame calls."""
+    chain = [(0, E(desc.ECHO)), (1, E(desc.EAX_REVERB))]
+    script = [("mix", 256)] * 2
+    script += [("send", 0, -1, 0.8, 0.5, 1.0), ("send", 1, -1, 1.0, 1.0, 0.3), ("send", 2, -1, 0.9, 0.25, 0.6),
+               ("send", 0, 0, 1.0, 0.4, 0.7), ("send", 1, 1, 0.7, 0.2, 1.0), ("send", 2, 1, 1.0, 1.0, 0.5), ("send", 3, 0, 0.5, 1.0, 1.0),
+               ("apply",)]
+    script += [("mix", 256), ("mix", 256), ("mix", 1), ("mix", 99), ("mix", 2500)]
+    # filters off again on some sends, other ones switched on
+    script += [("send", 0, -1, 1.0, 1.0, 1.0), ("send", 0, 0, 1.0, 1.0, 1.0), ("send", 4, 1, 1.0, 0.1, 0.1), ("apply",)]
+    script += [("mix", 1), ("mix", 256), ("mix", 256)]
+    # every filter off: back on the fused path, histories must have followed
+    script += [("send", i, s, 1.0, 1.0, 1.0) for i in range(5) for s in (-1, 0, 1)] + [("apply",)]
+    script += [("mix", 256), ("mix", 1), ("send", 2, -1, 1.0, 0.5, 0.5), ("apply",), ("mix", 256)]
+    run_batch(desc.FMT_STEREO, 48000, 2, [chain] * 5, script)
+
+
+def test_send_filters_null_slot_and_formats():
+    """A null slot's send is disabled and its filter history frozen; 5.1 has six input channels per send."""
+    setups = [[(0, E(desc.NULL)), (1, E(desc.CHORUS))], [(0, E(desc.REVERB)), (1, E(desc.NULL))]]
+    script = [("send", 0, 0, 1.0, 0.3, 0.3), ("send", 0, 1, 1.0, 0.6, 1.0), ("send", 1, -1, 1.0, 0.9, 0.2), ("send", 1, 1, 0.4, 0.5, 0.5),
+              ("apply",), ("mix", 256), ("mix", 200),
+              ("set", 0, 0, E(desc.EQUALIZER)), ("set", 1, 1, E(desc.RING_MODULATOR)), ("apply",), ("mix", 256), ("mix", 256)]
+    run_batch(desc.FMT_5POINT1, 44100, 2, setups, script)
+    run_batch(desc.FMT_MONO, 48000, 2, setups, script)

@@ -59,32 +59,7 @@ def test_rates(rate):
         compare(desc.FMT_STEREO, rate, 1, [(0, make_effect(t))], [256] * 3)
 
 
-FIELDS = {
-    desc.CHORUS: dict(waveform=(0, 1), phase=(-180, 180), rate=(0.0, 10.0), depth=(0.0, 1.0), feedback=(-1.0, 1.0), delay=(0.0, 0.016)),
-    desc.FLANGER: dict(waveform=(0, 1), phase=(-180, 180), rate=(0.0, 10.0), depth=(0.0, 1.0), feedback=(-1.0, 1.0), delay=(0.0, 0.004)),
-    desc.DISTORTION: dict(edge=(0.0, 1.0), gain=(0.01, 1.0), low_pass_cutoff=(80.0, 24000.0), eq_center=(80.0, 24000.0), eq_bandwidth=(80.0, 24000.0)),
-    desc.ECHO: dict(delay=(0.0, 0.207), lr_delay=(0.0, 0.404), damping=(0.0, 0.99), feedback=(0.0, 1.0), spread=(-1.0, 1.0)),
-    desc.EQUALIZER: dict(low_gain=(0.126, 7.943), low_cutoff=(50.0, 800.0), mid1_gain=(0.126, 7.943), mid1_center=(200.0, 3000.0), mid1_width=(0.01, 1.0),
-                         mid2_gain=(0.126, 7.943), mid2_center=(1000.0, 8000.0), mid2_width=(0.01, 1.0), high_gain=(0.126, 7.943), high_cutoff=(4000.0, 16000.0)),
-    desc.RING_MODULATOR: dict(frequency=(0.0, 8000.0), high_pass_cutoff=(0.0, 24000.0), waveform=(0, 2)),
-    desc.EAX_REVERB: dict(density=(0.0, 1.0), diffusion=(0.0, 1.0), gain=(0.0, 1.0), gain_hf=(0.0, 1.0), gain_lf=(0.0, 1.0), decay_time=(0.1, 20.0),
-                          decay_hf_ratio=(0.1, 2.0), decay_lf_ratio=(0.1, 2.0), reflections_gain=(0.0, 3.16), reflections_delay=(0.0, 0.3),
-                          late_reverb_gain=(0.0, 10.0), late_reverb_delay=(0.0, 0.1), echo_time=(0.075, 0.25), echo_depth=(0.0, 1.0),
-                          modulation_time=(0.04, 4.0), modulation_depth=(0.0, 1.0), air_absorption_gain_hf=(0.892, 1.0), hf_reference=(1000.0, 20000.0),
-                          lf_reference=(20.0, 1000.0)),
-}
-
-
-def random_effect(rng, t):
-    """Every field uniform in its [min, max] (BASELINE config 4's parameter randomisation)."""
-    over = {}
-    for k, (lo, hi) in FIELDS.get(t, {}).items():
-        over[k] = rng.randint(lo, hi) if isinstance(lo, int) else rng.uniform(lo, hi)
-    if t in (desc.EAX_REVERB, desc.REVERB):
-        over["reflections_pan"] = [rng.uniform(-1, 1) for _ in range(3)]
-        over["late_reverb_pan"] = [rng.uniform(-1, 1) for _ in range(3)]
-        over["decay_hf_limit"] = rng.random() < 0.5
-    return make_effect(t, **over)
+from oalsfxpp_amd.workloads import FIELDS, random_effect  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(24))
