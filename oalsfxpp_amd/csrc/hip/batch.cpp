@@ -83,6 +83,11 @@ struct oalsfx_batch {
     size_t io_capacity = 0;
 
     hipStream_t stream = nullptr;
+    // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
+    // is populated they run side by side on these streams, forked from and joined to the launch stream with events
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[2] = {nullptr, nullptr};
     const char* error = "";
     std::string error_store;
 
@@ -323,29 +328,57 @@ bool ensure_mixbuf(oalsfx_batch* b)
     return b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
 }
 
+int debug_flags()
+{
+    static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
+    return v;
+}
+
+struct ScopedTiming {
+    oalsfx_batch* b; hipStream_t stream; TimedLaunch tl{};
+    ScopedTiming(oalsfx_batch* b_, int type, hipStream_t s) : b(b_), stream(s)
+    {
+        if (!b->timing) return;
+        hipEventCreate(&tl.start);
+        hipEventCreate(&tl.stop);
+        tl.type = type;
+        hipEventRecord(tl.start, stream);
+    }
+    ~ScopedTiming()
+    {
+        if (!b->timing) return;
+        hipEventRecord(tl.stop, stream);
+        b->timed.push_back(tl);
+    }
+};
+
+constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
+
 void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
 {
     const int count = b->list_count[slot][type];
     if (count == 0) return;
     if (type == OALSFX_NULL && (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) == 0) return; // a null effect in the middle of the chain does nothing
     const int* list = b->d_lists + b->list_offset[slot][type];
-    TimedLaunch tl{};
-    if (b->timing) {
-        hipEventCreate(&tl.start);
-        hipEventCreate(&tl.stop);
-        tl.type = type;
-        hipEventRecord(tl.start, stream);
-    }
+    ScopedTiming timing(b, type, stream);
     if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) {
-        static const int debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
         const bool expect_steady = b->unsettled[slot][type] == 0 && (ctx.frames & 63) == 0;
-        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | (debug_flags << 8), expect_steady, stream);
+        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | ((debug_flags() & 0xFF) << 8), expect_steady, stream);
     }
     else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
-    if (b->timing) {
-        hipEventRecord(tl.stop, stream);
-        b->timed.push_back(tl);
-    }
+}
+
+// All ring-light effect types of a slot in one grid: their instance lists are adjacent in d_lists (types in
+// ascending order, the two reverb types last).
+void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+{
+    const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
+    const int first_type = null_has_duty ? OALSFX_NULL : OALSFX_NULL + 1;
+    int count = 0;
+    for (int t = first_type; t < OALSFX_REVERB; ++t) count += b->list_count[slot][t];
+    if (count == 0) return;
+    ScopedTiming timing(b, kTimedWaveEffects, stream);
+    oalsfx_hip::launch_wave_effects(ctx, slot, b->d_lists + b->list_offset[slot][first_type], count, flags, stream);
 }
 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
@@ -393,7 +426,37 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0) |
                               (filtered ? oalsfx_hip::kFiltered : 0);
             ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
-            for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) launch_type(b, t, ctx, s, flags, stream);
+            const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
+            int light = 0;
+            for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) light += b->list_count[s][t];
+            const bool group_on[3] = {light > 0, b->list_count[s][OALSFX_REVERB] > 0, b->list_count[s][OALSFX_EAX_REVERB] > 0};
+            const bool fork = (group_on[0] + group_on[1] + group_on[2]) > 1 && !(debug_flags() & 0x20000);
+            if (fork && !b->hip_ok(hipEventRecord(b->ev_fork, stream), "hipEventRecord")) return false;
+            int side = 0;
+            bool main_taken = false;
+            for (int g = 0; g < 3; ++g) {
+                if (!group_on[g]) continue;
+                hipStream_t gs = stream;
+                if (fork && main_taken) {
+                    gs = b->side_stream[side];
+                    if (!b->hip_ok(hipStreamWaitEvent(gs, b->ev_fork, 0), "hipStreamWaitEvent")) return false;
+                }
+                if (g == 0) {
+                    if (debug_flags() & 0x10000) {
+                        for (int t = 0; t < OALSFX_REVERB; ++t) launch_type(b, t, ctx, s, flags, gs); // first-version kernels, one launch per type
+                    } else {
+                        launch_wave_group(b, ctx, s, flags, gs);
+                    }
+                } else {
+                    launch_type(b, g == 1 ? OALSFX_REVERB : OALSFX_EAX_REVERB, ctx, s, flags, gs);
+                }
+                if (gs != stream) {
+                    if (!b->hip_ok(hipEventRecord(b->ev_join[side], gs), "hipEventRecord")) return false;
+                    if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_join[side], 0), "hipStreamWaitEvent")) return false;
+                    ++side;
+                }
+                main_taken = true;
+            }
         }
         done += n;
     }
@@ -456,6 +519,11 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     }
 
     bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; k < 2; ++k) {
+        ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->side_stream[k], hipStreamNonBlocking), "hipStreamCreate");
+        ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming), "hipEventCreate");
+    }
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_params), total * sizeof(oalsfx_slot_params)), "hipMalloc(params)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_slot_state)), "hipMalloc(state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
@@ -479,10 +547,17 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     if (!b) return;
     hipSetDevice(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
+    for (int k = 0; k < 2; ++k)
+        if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    for (int k = 0; k < 2; ++k) {
+        if (b->side_stream[k]) hipStreamDestroy(b->side_stream[k]);
+        if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);
+    }
+    if (b->ev_fork) hipEventDestroy(b->ev_fork);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
@@ -667,8 +742,10 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
     int n = 0;
     double ms = 0.0;
+    // the ring-light types share one launch per slot: asking for any of them reads that launch
+    const int key = (effect_type < OALSFX_REVERB && !(debug_flags() & 0x10000)) ? kTimedWaveEffects : effect_type;
     for (auto& t : b->timed) {
-        if (t.type != effect_type) continue;
+        if (t.type != key) continue;
         if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return 0;
         float e = 0.0F;
         if (!b->hip_ok(hipEventElapsedTime(&e, t.start, t.stop), "hipEventElapsedTime")) return 0;

@@ -47,6 +47,9 @@ constexpr int kWave = 64;
 // ---- launchers (defined next to their kernels) ----
 // expect_steady: host-side belief that every listed instance is in its steady state (speed hint only)
 void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream);
+// every ring-light effect type of a slot in one grid, one wavefront per listed instance (wave_effects.hip)
+void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+// the first version of those kernels, one lane per instance (simple_effects.hip); kept as a cross-check (OALSFX_DEBUG_FLAGS bit 16)
 void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.

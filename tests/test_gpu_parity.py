@@ -209,3 +209,16 @@ def test_send_filters_null_slot_and_formats():
               ("set", 0, 0, E(desc.EQUALIZER)), ("set", 1, 1, E(desc.RING_MODULATOR)), ("apply",), ("mix", 256), ("mix", 256)]
     run_batch(desc.FMT_5POINT1, 44100, 2, setups, script)
     run_batch(desc.FMT_MONO, 48000, 2, setups, script)
+
+
+@pytest.mark.parametrize("rate", [8000, 48000])
+def test_randomised_effects_odd_sizes(rate):
+    """BASELINE configs[3] in small: every non-null type with randomised properties (seed = instance), ragged call sizes
+    (1 frame, below and above a tile, above the 2048-frame chunk) and a mid-stream property change."""
+    import random
+    from oalsfxpp_amd.workloads import config4_type, random_effect
+    setups = [[(0, random_effect(random.Random(i), config4_type(i)))] for i in range(66)]
+    script = [("mix", 256), ("mix", 1), ("mix", 63), ("mix", 65), ("mix", 2100)]
+    script += [("set", i, 0, random_effect(random.Random(1000 + i), config4_type(i))) for i in range(0, 66, 3)] + [("apply",)]
+    script += [("mix", 256), ("mix", 130)]
+    run_batch(desc.FMT_STEREO, rate, 1, setups, script)
