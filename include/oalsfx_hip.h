@@ -101,6 +101,11 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
  * 256 contiguous bytes per wave instruction), `repeats` launches of k_hbm_sweep, reading (write == 0) or writing.  Used under
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE to calibrate those counters against a known byte count (profiles/README.md). */
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats);
+/* ---- measurement helper: the ring traffic of the steady-state reverb kernel without its arithmetic (k_stream_pattern:
+ * per instance 24 unaligned read streams and 24 aligned write streams of 256 frames per launch, `dwords_per_lane` = 1, 2 or 4
+ * consecutive dwords per lane = 256-, 512- or 1024-byte bursts; slabs `slab_floats` apart (>= 235520), instance i shifted by
+ * i * pos_skew samples inside its streams).  Returns the average launch time of `repeats` launches. */
+int oalsfx_debug_stream_pattern(int device_id, int instances, int dwords_per_lane, int repeats, int slab_floats, int pos_skew, double* avg_us);
 
 /* ---- host-only helpers (no GPU needed): the parameter-update path, exposed so the descriptors can be
  * checked against the reference and so the CPU oracle can be driven with identical parameters. */

@@ -73,5 +73,20 @@ def build_all(force=False, verbose=False):
     return OUT
 
 
+TOOL_SRC = os.path.join(ROOT, "tools", "oalsfx_wav.cpp")
+TOOL_OUT = os.path.join(ROOT, "tools", "oalsfx_wav")
+
+
+def build_tools(force=False):
+    """tools/oalsfx_wav: the WAV command-line program over oalsfxpp::Api, linked to the in-tree library."""
+    if not (force or _newer(TOOL_SRC, TOOL_OUT, (OUT, os.path.join(ROOT, "include", "oalsfxpp.h")))):
+        return TOOL_OUT
+    libdir = os.path.dirname(OUT)
+    subprocess.run(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), TOOL_SRC, "-L", libdir, "-loalsfx_hip",
+                    "-Wl,-rpath,$ORIGIN/../oalsfxpp_amd/csrc", "-o", TOOL_OUT], check=True)
+    return TOOL_OUT
+
+
 if __name__ == "__main__":
     print(build_all(force="--force" in sys.argv, verbose=True))
+    print(build_tools(force="--force" in sys.argv))

@@ -82,6 +82,7 @@ struct oalsfx_batch {
     float* d_io_dst = nullptr;
     size_t io_capacity = 0;
 
+    unsigned long long* d_timeline = nullptr;    // measurement only (OALSFX_DEBUG_TIMELINE=<file>)
     hipStream_t stream = nullptr;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
     // is populated they run side by side on these streams, forked from and joined to the launch stream with events
@@ -352,6 +353,7 @@ struct ScopedTiming {
     }
 };
 
+constexpr size_t kTimelineBytes = 64 * 4 * 96 * sizeof(unsigned long long); // 64 sampled workgroups x 4 waves x 96 stamps
 constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
 
 void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
@@ -404,6 +406,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.source_state = b->d_source_state;
     ctx.mixbuf = b->d_mixbuf;
     ctx.progress = b->d_progress;
+    ctx.timeline = b->d_timeline;
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
@@ -534,6 +537,10 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
+    if (ok && std::getenv("OALSFX_DEBUG_TIMELINE")) {
+        ok = b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_timeline), kTimelineBytes), "hipMalloc(timeline)");
+        ok = ok && b->hip_ok(hipMemsetAsync(b->d_timeline, 0, kTimelineBytes, b->stream), "hipMemsetAsync(timeline)");
+    }
     if (!ok) {
         g_last_error = b->error;
         oalsfx_batch_destroy(b);
@@ -549,6 +556,13 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     if (b->stream) hipStreamSynchronize(b->stream);
     for (int k = 0; k < 2; ++k)
         if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
+    if (b->d_timeline) {
+        // phase stamps of the last steady-state reverb launch, for scripts/timeline.py
+        std::vector<unsigned long long> h(kTimelineBytes / sizeof(unsigned long long));
+        if (hipMemcpy(h.data(), b->d_timeline, kTimelineBytes, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE* f = std::fopen(std::getenv("OALSFX_DEBUG_TIMELINE"), "wb")) { std::fwrite(h.data(), 1, kTimelineBytes, f); std::fclose(f); }
+        hipFree(b->d_timeline);
+    }
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
@@ -769,6 +783,30 @@ int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, i
     const bool ok = hipDeviceSynchronize() == hipSuccess;
     (void)hipFree(buf);
     (void)hipFree(sink);
+    return ok ? 1 : 0;
+}
+
+int oalsfx_debug_stream_pattern(int device_id, int instances, int dwords_per_lane, int repeats, int slab_floats, int pos_skew, double* avg_us)
+{
+    if (hipSetDevice(device_id) != hipSuccess || instances <= 0 || repeats <= 0) return 0;
+    if (dwords_per_lane != 1 && dwords_per_lane != 2 && dwords_per_lane != 4) return 0;
+    float* slabs = nullptr;
+    if (slab_floats < 235520) return 0;
+    const size_t bytes = static_cast<size_t>(instances) * slab_floats * sizeof(float);
+    if (hipMalloc(reinterpret_cast<void**>(&slabs), bytes) != hipSuccess) return 0;
+    (void)hipMemset(slabs, 0, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 8; ++r) oalsfx_hip::launch_stream_pattern(slabs, instances, dwords_per_lane, 256u * r, slab_floats, pos_skew, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_stream_pattern(slabs, instances, dwords_per_lane, 256u * (8 + r), slab_floats, pos_skew, nullptr);
+    hipEventRecord(e1, nullptr);
+    bool ok = hipEventSynchronize(e1) == hipSuccess;
+    float ms = 0.0F;
+    ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (avg_us) *avg_us = ms * 1e3 / repeats;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipFree(slabs);
     return ok ? 1 : 0;
 }
 

@@ -30,6 +30,7 @@ struct KernelCtx {
     int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
     long long io_stride;                // floats between consecutive instances in dst
     long long src_stride;               // floats between consecutive instances in src / wet_src
+    unsigned long long* timeline;       // measurement only (OALSFX_DEBUG_TIMELINE): phase time stamps of sampled workgroups, else nullptr
 };
 
 // Flags of one launch: which duties of the mix loop this slot's kernel performs.
@@ -56,6 +57,7 @@ void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* l
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
                          hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
+void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream);
 void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 
 #if defined(__HIPCC__)

@@ -208,9 +208,16 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CH, int NW>
+template <int CH, int NW, bool TL = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
+    // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
+    int ts_i = 0;
+    auto stamp = [&]() {
+        if (TL && (blockIdx.x & 63) == 0 && (threadIdx.x & 63) == 0 && ts_i < 96)
+            ctx.timeline[((blockIdx.x >> 6) * NW + (threadIdx.x >> 6)) * 96 + ts_i++] = clock64();
+    };
+    stamp();
     static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
     constexpr int kFloats = Lds<CH>::kFloats; // sized for the general path, which non-steady instances fall back to below
     __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
@@ -240,34 +247,50 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     oalsfx_reverb_state& S = SS.u.reverb;
     GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
 
-    // ---- is this instance in its steady state for the whole buffer? (see k_reverb_steady) ----
-    bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (SS.seen_seq == SP.update_seq) && (S.fade_count >= OALSFX_RV_FADE_SAMPLES) &&
-              (P.mod_depth == 0.0F) && (S.mod_filter == 0.0F);
+    // ---- everything the steady-state path needs from the descriptors, requested in one go: the loads below do not
+    // depend on each other, so the prologue costs one memory round trip after the list entry instead of three
+    const int l4 = lane & 3;
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
     const bool q_valid = lane < 8 * CH;
-    float g_cur = 0.0F;
-    if (go) {
-        float g_tgt = 0.0F;
-        if (q_valid) {
-            g_cur = q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan];
-            g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
-        }
+    const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb; // per-lane (vector) reads of the parameter block
+    const oalsfx_source_params& SG = ctx.source[inst];
+    const unsigned v_seen = SS.seen_seq;
+    const int v_fade = S.fade_count;
+    const float v_modf = S.mod_filter;
+    const int v_offset = S.offset;
+    const int v_tap = (&S.cur_early_tap[0])[min(lane, 23)];
+    const int v_ring_off = PG.ring_off[min(lane >> 2, 4)], v_ring_len = PG.ring_len[min(lane >> 2, 4)];
+    const int v_ring_len5 = PG.ring_len[min(lane, 4)];
+    const float v_gcur = q_valid ? (q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan]) : 0.0F;
+    const float v_gtgt = q_valid ? (q_stage ? PG.late_pan[q_line][q_chan] : PG.early_pan[q_line][q_chan]) : 0.0F;
+    const float v_ecoef = PG.early_tap_coeff[l4], v_elcoef = PG.early_line_coeff[l4];
+    const float v_tl0 = PG.t60_lf[l4][0], v_tl1 = PG.t60_lf[l4][1], v_tl2 = PG.t60_lf[l4][2];
+    const float v_th0 = PG.t60_hf[l4][0], v_th1 = PG.t60_hf[l4][1], v_th2 = PG.t60_hf[l4][2];
+    const float v_tmid = PG.t60_mid[l4];
+    const float v_lpx0 = S.lp[l4].x[0], v_lpx1 = S.lp[l4].x[1], v_lpy0 = S.lp[l4].y[0], v_lpy1 = S.lp[l4].y[1];
+    const float v_hpy0 = S.hp[l4].y[0], v_hpy1 = S.hp[l4].y[1];
+    const float v_t60x = S.t60[l4][0][0], v_t60o1 = S.t60[l4][0][1], v_t60o2 = S.t60[l4][1][1];
+    const float v_gdir = SG.direct.gains[(lane >> 1) & 1][lane & 1];
+    const float v_gaux = SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
+
+    // ---- is this instance in its steady state for the whole buffer? ----
+    bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
+              (P.mod_depth == 0.0F) && (v_modf == 0.0F);
+    const float g_cur = v_gcur;
+    {
         // the last chunk of the buffer has the smallest ramp counter, hence the largest step: no ramp there, no ramp anywhere
         const int last_chunk = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
-        const float step = (g_tgt - g_cur) * (1.0F / static_cast<float>(last_chunk));
+        const float step = (v_gtgt - g_cur) * (1.0F / static_cast<float>(last_chunk));
         if (__ballot(q_valid && fabsf(step) > FLT_EPSILON) != 0ULL) go = false;
-    }
-    if (go) {
-        if (lane < 24) utu[ut::TAP4 + lane] = 4u * static_cast<unsigned>((&S.cur_early_tap[0])[lane]);
-        if (lane == 0) utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
-        wave_sync();
-        const unsigned tp = (lane < 24) ? utu[ut::TAP4 + lane] : 0xFFFFFFFFu;
-        const unsigned need = 512u + ((lane >> 2) == 3 ? utu[ut::FEED4] : 0u);
-        go = __ballot(tp >= need) == ~0ULL;
+        // every tap at least two tiles away from its write position (late taps: from the late feed position)
+        const unsigned tp = (lane < 24) ? 4u * static_cast<unsigned>(v_tap) : 0xFFFFFFFFu;
+        const unsigned need = 512u + ((lane >> 2) == 3 ? 4u * static_cast<unsigned>(P.late_feed_tap) : 0u);
+        if (__ballot(tp >= need) != ~0ULL) go = false;
     }
     if (lane == 0) {
         go_all[wib] = go ? 1 : 0;
     }
+    stamp(); // [1] descriptors read, steady-state test done
 
     unsigned aud_dir = 0, aud_aux = 0, aud_out = 0;
     int offset = 0;
@@ -277,49 +300,42 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const float b2a = 0.288675134595F;
     if (go) {
         // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
-        if (lane < 20) {
-            const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb;
-            const int r = lane >> 2, j = lane & 3;
-            utu[ut::LO + lane] = static_cast<unsigned>(PG.ring_off[r] + j * PG.ring_len[r]) << 2;
-            if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(PG.ring_len[lane] - 1) << 2;
-            if (lane < 4) {
-                utf[ut::ECOEF + lane] = PG.early_tap_coeff[lane];
-                utf[ut::ELCOEF + lane] = PG.early_line_coeff[lane];
-                utf[ut::TL0 + lane] = PG.t60_lf[lane][0];
-                utf[ut::TL1 + lane] = PG.t60_lf[lane][1];
-                utf[ut::TH0 + lane] = PG.t60_hf[lane][0];
-                utf[ut::TH1 + lane] = PG.t60_hf[lane][1];
-                float* ch = chain_all[wib][lane];
-                ch[coop::LPX0] = S.lp[lane].x[0]; ch[coop::LPX1] = S.lp[lane].x[1];
-                ch[coop::LPY0] = S.lp[lane].y[0]; ch[coop::LPY1] = S.lp[lane].y[1];
-                ch[coop::HPY0] = S.hp[lane].y[0]; ch[coop::HPY1] = S.hp[lane].y[1];
-                ch[coop::T60X] = S.t60[lane][0][0]; ch[coop::T60O1] = S.t60[lane][0][1]; ch[coop::T60O2] = S.t60[lane][1][1];
-                ch[coop::LP_A1] = PG.lp.a1; ch[coop::LP_A2] = PG.lp.a2; ch[coop::HP_A1] = PG.hp.a1; ch[coop::HP_A2] = PG.hp.a2;
-                ch[coop::T_L2] = PG.t60_lf[lane][2]; ch[coop::T_H2] = PG.t60_hf[lane][2]; ch[coop::T_MID] = PG.t60_mid[lane];
-            }
-            const oalsfx_source_params& SG = ctx.source[inst];
-            if (lane < 4) utf[ut::GDIR + lane] = SG.direct.gains[lane >> 1][lane & 1];
-            if (lane < 8) utf[ut::GAUX + lane] = SG.aux[slot].gains[lane >> 2][lane & 3];
+        // (flags >> 8) & 32 / 64: timing experiment only (OALSFX_DEBUG_FLAGS), taps rounded to 128 / 256 bytes, results wrong
+        if (lane < 24) utu[ut::TAP4 + lane] = (4u * static_cast<unsigned>(v_tap)) & ((flags & (64 << 8)) ? ~255u : (flags & (32 << 8)) ? ~127u : ~0u);
+        if (lane < 20) utu[ut::LO + lane] = static_cast<unsigned>(v_ring_off + l4 * v_ring_len) << 2;
+        if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(v_ring_len5 - 1) << 2;
+        if (lane < 4) {
+            utf[ut::ECOEF + lane] = v_ecoef;
+            utf[ut::ELCOEF + lane] = v_elcoef;
+            utf[ut::TL0 + lane] = v_tl0;
+            utf[ut::TL1 + lane] = v_tl1;
+            utf[ut::TH0 + lane] = v_th0;
+            utf[ut::TH1 + lane] = v_th1;
+            float* ch = chain_all[wib][lane];
+            ch[coop::LPX0] = v_lpx0; ch[coop::LPX1] = v_lpx1;
+            ch[coop::LPY0] = v_lpy0; ch[coop::LPY1] = v_lpy1;
+            ch[coop::HPY0] = v_hpy0; ch[coop::HPY1] = v_hpy1;
+            ch[coop::T60X] = v_t60x; ch[coop::T60O1] = v_t60o1; ch[coop::T60O2] = v_t60o2;
+            ch[coop::LP_A1] = P.lp.a1; ch[coop::LP_A2] = P.lp.a2; ch[coop::HP_A1] = P.hp.a1; ch[coop::HP_A2] = P.hp.a2;
+            ch[coop::T_L2] = v_tl2; ch[coop::T_H2] = v_th2; ch[coop::T_MID] = v_tmid;
+            utf[ut::GDIR + lane] = v_gdir;
         }
+        if (lane < 8) utf[ut::GAUX + lane] = v_gaux;
         if (lane == 0) {
+            utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
             utf[ut::MISC + 0] = P.density_gain; utf[ut::MISC + 1] = P.ap_feed_coeff; utf[ut::MISC + 2] = P.mix_x; utf[ut::MISC + 3] = P.mix_y;
             utf[ut::LPB + 0] = P.lp.b0; utf[ut::LPB + 1] = P.lp.b1; utf[ut::LPB + 2] = P.lp.b2; utf[ut::LPB + 3] = 0.0F;
             utf[ut::HPB + 0] = P.hp.b0; utf[ut::HPB + 1] = P.hp.b1; utf[ut::HPB + 2] = P.hp.b2; utf[ut::HPB + 3] = 0.0F;
         }
         if (q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
-        typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
-        ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-            for (int o = 0; o < CH; ++o) aud_dir |= audible(SRC.direct.gains[c][o]) ? 1u << (c * 2 + o) : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) aud_aux |= audible(SRC.aux[slot].gains[c][k]) ? 1u << (c * 4 + k) : 0u;
-        }
+        aud_dir = static_cast<unsigned>(__ballot(lane < 4 && audible(v_gdir)));   // bit c * 2 + o
+        aud_aux = static_cast<unsigned>(__ballot(lane < 8 && audible(v_gaux)));   // bit c * 4 + k
+        if (CH == 1) { aud_dir &= 1u; aud_aux &= 0xFu; }
         aud_out = static_cast<unsigned>(__ballot(q_valid && audible(g_cur)));
         if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
                                 ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
-        offset = S.offset;
+        offset = v_offset;
+        wave_sync(); // this wave's table is complete: the first tile's requests below read it
     }
 
     // Software pipeline: inputs of tile k+1 are requested before tile k is computed (every tap is >= 2 tiles away).
@@ -363,7 +379,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     float* crow2 = lds_all[cw] + (2 * 4 + cc) * kRow;
     float* cdat = chain_all[cw][cc];
 
+    stamp(); // [2] tables written
+    // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
+    if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
+    stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
+    stamp(); // [4]
     bool any_go = false;
 #pragma unroll
     for (int k = 0; k < NW; ++k) any_go |= go_all[k] != 0;
@@ -371,7 +392,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
     // put the same phase on the same SIMD
     const int duty = (wib - static_cast<int>(blockIdx.x)) & (NW - 1);
-    if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
 
     const int tiles = any_go ? frames >> 6 : 0; // a workgroup without a steady instance skips the cooperative loop altogether
     for (int tile = 0; tile < tiles; ++tile) {
@@ -428,7 +448,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                 ch[coop::LPX1] = row(0, lane)[4 + 62]; ch[coop::LPX0] = row(0, lane)[4 + 63];
             }
         }
+        stamp();
         lds_barrier();
+        stamp();
         // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
         if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
@@ -436,7 +458,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
         }
+        stamp();
         lds_barrier();
+        stamp();
         int xg = 2;
         if (eax) {
             // ---------------- P2: feed-forward half of the second shelf ----------------
@@ -448,14 +472,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                 const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
                 row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
             }
-            lds_barrier();
+            stamp();
+        lds_barrier();
+        stamp();
             // ---------------- C2 (wave 1) ----------------
             if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
                 biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
             }
-            lds_barrier();
+            stamp();
+        lds_barrier();
+        stamp();
             xg = 0;
         }
         // ---------------- P3: main delay write, early reflections, late taps, T60 first feed-forward ----------------
@@ -500,7 +528,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             }
             if (lane < 4) chain_all[wib][lane][coop::T60X] = row(0, lane)[4 + 63];
         }
+        stamp();
         lds_barrier();
+        stamp();
         // ---------------- C3 (wave 2): first T60 section ----------------
         if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float prev = cdat[coop::T60O1];
@@ -508,7 +538,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
             cdat[coop::T60O1] = prev;
         }
+        stamp();
         lds_barrier();
+        stamp();
         // ---------------- P4: second T60 feed-forward ----------------
         if (go) {
             const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
@@ -519,14 +551,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
             row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
         }
+        stamp();
         lds_barrier();
+        stamp();
         // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
         if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             float prev = cdat[coop::T60O2];
             first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
         }
+        stamp();
         lds_barrier();
+        stamp();
         // ---------------- P5: late all-pass, ring writes, outputs ----------------
         if (go) {
             const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
@@ -557,6 +593,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             }
             wave_sync(); // ring stores of this tile precede the loads of the tile after next (program order)
         }
+        stamp();
     }
 
     // ---- hand the state back ----
@@ -588,6 +625,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         whole.progress = nullptr; // nothing of this buffer has been processed for this instance
         reverb_general_call<CH>(&whole, slot, inst, flags & 0xFF, lds, lane);
     }
+    stamp(); // state handed back
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1197,6 +1235,7 @@ void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, i
         // otherwise the others are deferred to the general kernel below, which runs them at full occupancy.
         const int f = flags | (expect_steady ? 0 : kDeferGeneral);
         if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
+        else if (ctx.timeline) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, true>), grid, block, 0, stream, ctx, slot, list, count, f);
         else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
         if (expect_steady) return;
     } else {

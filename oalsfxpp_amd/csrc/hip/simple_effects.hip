@@ -452,4 +452,58 @@ void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStre
     hipLaunchKernelGGL(k_hbm_sweep, dim3(256 * 8), dim3(256), 0, stream, buf, floats, write, sink);
 }
 
+
+// ---- measurement helper: the ring traffic of the steady-state reverb kernel without its arithmetic.  One wavefront per
+// "instance" (a 942 080-byte slab like a 48 kHz reverb), 24 read streams at unaligned positions and 24 aligned write
+// streams, 256 frames per launch, V consecutive dwords per lane and stream (V = 1: 256-byte bursts like the kernel today,
+// 2: 512 bytes, 4: 1 KiB).  Shows what the memory system sustains for this pattern and what longer bursts would buy.
+template <int V>
+__global__ __launch_bounds__(256) void k_stream_pattern(float* slabs, int instances, unsigned pos0, size_t slab_floats, int pos_skew)
+{
+    const int lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= instances) return;
+    float* slab = slabs + static_cast<size_t>(inst) * slab_floats;
+    pos0 += static_cast<unsigned>(inst * pos_skew); // instances at different ring positions
+    constexpr int kSteps = 256 / (64 * V);
+    typedef float vf __attribute__((ext_vector_type(V)));
+    vf cur[24];
+    auto issue = [&](int step, vf* dst) {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            const unsigned p = (pos0 + step * 64 * V + lane * V + 13u + 37u * s) & 4095u; // unaligned, differs per stream
+            const float* q = slab + s * 4608 + p;
+#pragma unroll
+            for (int k = 0; k < V; ++k) dst[s][k] = q[k]; // V consecutive dwords (not 16-byte aligned: as separate dwords)
+        }
+    };
+    issue(0, cur);
+    for (int step = 0; step < kSteps; ++step) {
+        vf nxt[24];
+        if (step + 1 < kSteps) issue(step + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        vf acc = cur[0];
+#pragma unroll
+        for (int s = 1; s < 24; ++s) acc = acc + cur[s];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            const unsigned p = (pos0 + step * 64 * V + lane * V) & 4095u; // aligned like the kernel's writes
+            vf* q = reinterpret_cast<vf*>(slab + 110592 + s * 4608 + p);
+            *q = acc + static_cast<float>(s);
+        }
+        if (step + 1 < kSteps) {
+#pragma unroll
+            for (int s = 0; s < 24; ++s) cur[s] = nxt[s];
+        }
+    }
+}
+
+void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream)
+{
+    const dim3 grid((instances + 3) / 4), block(256);
+    if (dwords_per_lane == 1) hipLaunchKernelGGL(k_stream_pattern<1>, grid, block, 0, stream, slabs, instances, pos0, slab_floats, pos_skew);
+    else if (dwords_per_lane == 2) hipLaunchKernelGGL(k_stream_pattern<2>, grid, block, 0, stream, slabs, instances, pos0, slab_floats, pos_skew);
+    else hipLaunchKernelGGL(k_stream_pattern<4>, grid, block, 0, stream, slabs, instances, pos0, slab_floats, pos_skew);
+}
+
 } // namespace oalsfx_hip

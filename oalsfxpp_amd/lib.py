@@ -42,6 +42,7 @@ SIGNATURES = {
     "oalsfx_batch_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "oalsfx_batch_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
+    "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),
     "oalsfx_host_effect_normalize": (None, [C.POINTER(desc.Effect)]),
     "oalsfx_host_derive_slot": (C.c_int, [C.c_int, C.c_int, C.POINTER(desc.Effect), C.POINTER(desc.SlotParams)]),
