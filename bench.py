@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default 4096; 8192 for config4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
+    ap.add_argument("--preset", type=int, default=-1, help="experiment: every instance uses EFX preset N")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"],
                     help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain) or configs[3] "
                          "(11 effect types, randomised properties; 8192 instances unless --instances is given)")
@@ -122,7 +123,15 @@ def main():
     n = args.instances or (8192 if args.workload == "config4" else 4096)
     workload = "config2-presets" if args.preset_mix else args.workload
     batch = Batch(n, desc.FMT_STEREO, 48000, workloads.effect_count(workload), device_id=local_rank)
-    workloads.setup(batch, workload, first_instance=rank * n)
+    if args.preset >= 0:
+        e = lib.effect_defaults(desc.EAX_REVERB)
+        name, e.props.reverb = lib.preset(args.preset)
+        batch.set_effect(0, e)
+        batch.apply_changes()
+        workload = "config2-presets"
+        WORKLOADS[workload] = "{n} EAX-reverb instances per GPU, all EFX preset " + name
+    else:
+        workloads.setup(batch, workload, first_instance=rank * n)
 
     # inputs resident in HBM: a ring of pre-generated buffers, one output buffer
     n_in = 8
@@ -157,7 +166,8 @@ def main():
 
     # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
     kernels = {}
-    timed = {"wave_effects (all ring-light types of a slot, one launch)": desc.CHORUS, "reverb": desc.REVERB, "eax_reverb": desc.EAX_REVERB}
+    timed = {"wave_effects (all ring-light types of a slot, one launch)": desc.CHORUS, "reverb steady-state": desc.REVERB,
+             "eax_reverb steady-state": desc.EAX_REVERB, "reverb + eax_reverb general": desc.REVERB + 16}
     for name, t in timed.items():
         l, ms = batch.kernel_timing_read(t)
         if l:
@@ -169,7 +179,7 @@ def main():
         bytes_per_step = sum(workloads.BYTES_PER_FRAME[workloads.config4_type(rank * n + i)] for i in range(n)) * FRAMES
     else:
         bytes_per_step = BYTES_PER_FRAME * frames_per_launch
-    if workload.startswith("config2"):
+    if workload == "config2":
         # the headline: the dominant kernel alone
         launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
     else:

@@ -92,8 +92,9 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
 
 /* ---- HIP-event timing of the dominant kernel, measured on the launch stream.  While enabled, every
  * effect kernel launch is bracketed by events; read() returns the number of launches of `effect_type`
- * since enable and their summed duration in milliseconds.  Reverb and EAX reverb have a launch of their own;
- * every other effect type of a slot shares one launch (k_wave_effects), which any of those types reads. */
+ * since enable and their summed duration in milliseconds.  Every effect type of a slot other than the two reverbs shares
+ * one launch (k_wave_effects), which any of those types reads.  Reverbs: `effect_type` reads that type's steady-state
+ * kernel, `effect_type + 16` the general kernel, which both reverb types share (the groups run side by side). */
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
 

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -39,6 +40,8 @@ struct RingPool {
 
 struct TimedLaunch { hipEvent_t start, stop; int type; };
 
+constexpr int kSideStreams = 2; // ring-light effects, steady-state reverbs, general reverbs: three kernel groups side by side at most
+
 } // namespace
 
 struct oalsfx_batch {
@@ -57,6 +60,9 @@ struct oalsfx_batch {
     std::vector<uint8_t> inst_dirty;              // [n]
     std::vector<int> since_update;                // [n*slots] frames mixed since the slot's last parameter update (capped)
     int unsettled[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // reverb instances per list not yet believed steady
+    bool close_taps[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // some reverb of the list has a tap between one and two tiles
+    bool modulated[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};  // some reverb of the list has, or had, a modulated late line (sticky:
+                                                               // the depth smoother keeps moving long after the depth is set to 0)
     std::vector<int> dirty_list;
     bool lists_dirty = true;
     bool filters_active = false;
@@ -72,8 +78,14 @@ struct oalsfx_batch {
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
     int* d_progress = nullptr;                    // [n*slots] hand-off between the steady-state and the general reverb kernel
+    // Per slot the list is: ring-light types in ascending order (list_offset / list_count per type), then the reverb instances
+    // believed steady (reverb, EAX reverb: list_offset / steady_count), then every other reverb instance of both types
+    // (general_offset / general_count).  list_count of a reverb type counts all its instances.
     int list_offset[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
+    int steady_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
+    int general_offset[OALSFX_MAX_SLOTS] = {};
+    int general_count[OALSFX_MAX_SLOTS] = {};
     std::map<size_t, RingPool> pools;
     std::vector<void*> chunks;
 
@@ -86,9 +98,9 @@ struct oalsfx_batch {
     hipStream_t stream = nullptr;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
     // is populated they run side by side on these streams, forked from and joined to the launch stream with events
-    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipStream_t side_stream[kSideStreams] = {};
     hipEvent_t ev_fork = nullptr;
-    hipEvent_t ev_join[2] = {nullptr, nullptr};
+    hipEvent_t ev_join[kSideStreams] = {};
     const char* error = "";
     std::string error_store;
 
@@ -161,18 +173,38 @@ void release_slab(oalsfx_batch* b, size_t idx)
 
 constexpr int kSettleFrames = 2 * OALSFX_RV_FADE_SAMPLES; // a cross-fade (128 frames) and the gain ramp of one call are over
 
-// Host-side belief about which reverb instances the steady-state kernel will fully process.  It only selects the
-// grid of the general kernel that follows (a speed hint); the kernels decide on the device from the real state.
+// Host-side belief about which reverb instances the steady-state kernel will fully process: they are listed first and go
+// to that kernel, the others straight to the general kernel (a speed hint; the steady-state kernel decides on the device
+// from the real state and falls back by itself).
 bool reverb_settled(const oalsfx_batch* b, size_t idx)
 {
     const oalsfx_reverb_params& p = b->h_params[idx].u.reverb;
-    if (b->since_update[idx] < kSettleFrames || p.mod_depth != 0.0F) return false;
+    if (b->since_update[idx] < kSettleFrames) return false;
+    const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
     for (int j = 0; j < 4; ++j) {
-        if (p.early_tap[j] < 128 || p.early_ap_off[j] < 128 || p.early_line_off[j] < 128 || p.late_ap_off[j] < 128 ||
-            p.late_line_off[j] < 128 || p.late_tap[j] < p.late_feed_tap + 128)
+        if (p.early_tap[j] < 64 || p.early_ap_off[j] < 64 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 64 ||
+            p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap + 64)
             return false;
     }
     return true;
+}
+
+// Speed hint for the steady-state reverb kernel: does any instance of a list have a tap distance of 64..127 samples?
+void rescan_close_taps(oalsfx_batch* b)
+{
+    for (int s = 0; s < b->slots; ++s)
+        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) b->close_taps[s][t] = false;
+    for (int i = 0; i < b->n; ++i)
+        for (int s = 0; s < b->slots; ++s) {
+            const oalsfx_slot_params& sp = b->h_params[static_cast<size_t>(i) * b->slots + s];
+            if (sp.type != OALSFX_REVERB && sp.type != OALSFX_EAX_REVERB) continue;
+            const oalsfx_reverb_params& p = sp.u.reverb;
+            int lo = 1 << 30;
+            for (int j = 0; j < 4; ++j)
+                lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
+            if (lo >= 64 && lo < 128) b->close_taps[s][sp.type] = true;
+            if (p.mod_depth != 0.0F) b->modulated[s][sp.type] = true;
+        }
 }
 
 void recount_unsettled(oalsfx_batch* b)
@@ -291,25 +323,38 @@ bool sync_params(oalsfx_batch* b)
     if (!upload_flagged(b, b->d_state, b->h_state_init.data(), up_state)) return false;
     if (!upload_flagged(b, b->d_source, b->h_source.data(), up_source)) return false;
 
+    if (settle_dirty) recount_unsettled(b); // may flag the list order as stale
     if (any_type_change || b->lists_dirty) {
         std::vector<int> lists(total);
         for (int s = 0; s < b->slots; ++s) {
             int off = 0;
-            for (int t = 0; t < OALSFX_TYPE_COUNT; ++t) {
-                b->list_offset[s][t] = s * b->n + off;
+            auto gather = [&](int t, int want_settled /* -1: any */) {
                 int cnt = 0;
-                // reverb lists: instances believed steady first, so that the 4-instance workgroups of the kernel are
-                // (almost all) either fully steady or fully transitional; the order has no effect on results
-                const bool reverb = (t == OALSFX_REVERB || t == OALSFX_EAX_REVERB);
-                for (int pass = 0; pass < (reverb ? 2 : 1); ++pass)
-                    for (int i = 0; i < b->n; ++i) {
-                        const size_t idx = static_cast<size_t>(i) * b->slots + s;
-                        if (b->h_params[idx].type != t) continue;
-                        if (reverb && reverb_settled(b, idx) != (pass == 0)) continue;
-                        lists[s * b->n + off + cnt++] = i;
-                    }
-                b->list_count[s][t] = cnt;
+                for (int i = 0; i < b->n; ++i) {
+                    const size_t idx = static_cast<size_t>(i) * b->slots + s;
+                    if (b->h_params[idx].type != t) continue;
+                    if (want_settled >= 0 && reverb_settled(b, idx) != (want_settled == 1)) continue;
+                    lists[s * b->n + off + cnt++] = i;
+                }
                 off += cnt;
+                return cnt;
+            };
+            for (int t = 0; t < OALSFX_REVERB; ++t) {
+                b->list_offset[s][t] = s * b->n + off;
+                b->list_count[s][t] = gather(t, -1);
+            }
+            // instances believed steady first: the 4-instance workgroups of the steady-state kernel get homogeneous work and
+            // the rest of both reverb types forms one list for the general kernel; the order has no effect on results
+            for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) {
+                b->list_offset[s][t] = s * b->n + off;
+                b->steady_count[s][t] = gather(t, 1);
+            }
+            b->general_offset[s] = s * b->n + off;
+            b->general_count[s] = 0;
+            for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) {
+                const int g = gather(t, 0);
+                b->general_count[s] += g;
+                b->list_count[s][t] = b->steady_count[s][t] + g;
             }
         }
         if (!upload_range(b, b->d_lists, lists.data(), 0, total)) return false;
@@ -317,7 +362,7 @@ bool sync_params(oalsfx_batch* b)
         if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return false;
         b->lists_dirty = false;
     }
-    if (settle_dirty) recount_unsettled(b);
+    rescan_close_taps(b);
     // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
     return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
 }
@@ -353,7 +398,8 @@ struct ScopedTiming {
     }
 };
 
-constexpr size_t kTimelineBytes = 64 * 4 * 96 * sizeof(unsigned long long); // 64 sampled workgroups x 4 waves x 96 stamps
+constexpr size_t kTimelineBytes = (64 * 4 + 64) * 96 * sizeof(unsigned long long); // 64 sampled workgroups x 4 waves x 96 stamps (steady-state kernel) + 64 sampled instances x 96 (general path)
+constexpr int kTimedGeneralOffset = 16; // TimedLaunch::type of a reverb type's general-kernel launches
 constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
 
 void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
@@ -361,13 +407,29 @@ void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int 
     const int count = b->list_count[slot][type];
     if (count == 0) return;
     if (type == OALSFX_NULL && (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) == 0) return; // a null effect in the middle of the chain does nothing
-    const int* list = b->d_lists + b->list_offset[slot][type];
     ScopedTiming timing(b, type, stream);
-    if (type == OALSFX_REVERB || type == OALSFX_EAX_REVERB) {
-        const bool expect_steady = b->unsettled[slot][type] == 0 && (ctx.frames & 63) == 0;
-        oalsfx_hip::launch_reverb(ctx, slot, list, count, flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | ((debug_flags() & 0xFF) << 8), expect_steady, stream);
-    }
-    else oalsfx_hip::launch_simple(type, ctx, slot, list, count, flags, stream);
+    oalsfx_hip::launch_simple(type, ctx, slot, b->d_lists + b->list_offset[slot][type], count, flags, stream);
+}
+
+// Can the steady-state kernel be used for this chunk at all?
+bool steady_kernel_usable(const KernelCtx& ctx) { return (ctx.frames & 63) == 0 && ctx.channels <= 2 && !(debug_flags() & 8); }
+
+void launch_reverb_steady_part(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+{
+    const int f = flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | ((debug_flags() & 0xFF) << 8);
+    ScopedTiming timing(b, type, stream);
+    oalsfx_hip::launch_reverb_steady(ctx, slot, b->d_lists + b->list_offset[slot][type], b->steady_count[slot][type], f, b->close_taps[slot][type],
+                                     b->modulated[slot][type], stream);
+}
+
+// The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of
+// the slot when the steady-state kernel cannot be used for this chunk (the two regions are adjacent in the list).
+void launch_reverb_general_part(oalsfx_batch* b, bool everything, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+{
+    const int offset = everything ? b->list_offset[slot][OALSFX_REVERB] : b->general_offset[slot];
+    const int count = b->general_count[slot] + (everything ? b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB] : 0);
+    ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
+    oalsfx_hip::launch_reverb_general(ctx, slot, b->d_lists + offset, count, flags | ((debug_flags() & 0xFF) << 8), stream);
 }
 
 // All ring-light effect types of a slot in one grid: their instance lists are adjacent in d_lists (types in
@@ -432,13 +494,20 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
             int light = 0;
             for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) light += b->list_count[s][t];
-            const bool group_on[3] = {light > 0, b->list_count[s][OALSFX_REVERB] > 0, b->list_count[s][OALSFX_EAX_REVERB] > 0};
-            const bool fork = (group_on[0] + group_on[1] + group_on[2]) > 1 && !(debug_flags() & 0x20000);
+            // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state kernel per reverb type
+            // (one after the other on one stream) and the general reverb kernel
+            const bool use_steady = steady_kernel_usable(ctx);
+            const int rs = use_steady ? b->steady_count[s][OALSFX_REVERB] : 0, es = use_steady ? b->steady_count[s][OALSFX_EAX_REVERB] : 0;
+            const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
+            const bool part_on[3] = {light > 0, rs + es > 0, reverbs - rs - es > 0};
+            int parts = 0;
+            for (bool on : part_on) parts += on;
+            const bool fork = parts > 1 && !(debug_flags() & 0x20000);
             if (fork && !b->hip_ok(hipEventRecord(b->ev_fork, stream), "hipEventRecord")) return false;
             int side = 0;
             bool main_taken = false;
             for (int g = 0; g < 3; ++g) {
-                if (!group_on[g]) continue;
+                if (!part_on[g]) continue;
                 hipStream_t gs = stream;
                 if (fork && main_taken) {
                     gs = b->side_stream[side];
@@ -450,8 +519,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                     } else {
                         launch_wave_group(b, ctx, s, flags, gs);
                     }
+                } else if (g == 1) {
+                    if (rs > 0) launch_reverb_steady_part(b, OALSFX_REVERB, ctx, s, flags, gs);
+                    if (es > 0) launch_reverb_steady_part(b, OALSFX_EAX_REVERB, ctx, s, flags, gs);
                 } else {
-                    launch_type(b, g == 1 ? OALSFX_REVERB : OALSFX_EAX_REVERB, ctx, s, flags, gs);
+                    launch_reverb_general_part(b, !use_steady, ctx, s, flags, gs);
                 }
                 if (gs != stream) {
                     if (!b->hip_ok(hipEventRecord(b->ev_join[side], gs), "hipEventRecord")) return false;
@@ -522,7 +594,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     }
 
     bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kSideStreams; ++k) {
         ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->side_stream[k], hipStreamNonBlocking), "hipStreamCreate");
         ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming), "hipEventCreate");
     }
@@ -554,7 +626,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     if (!b) return;
     hipSetDevice(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < kSideStreams; ++k)
         if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
     if (b->d_timeline) {
         // phase stamps of the last steady-state reverb launch, for scripts/timeline.py
@@ -567,7 +639,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kSideStreams; ++k) {
         if (b->side_stream[k]) hipStreamDestroy(b->side_stream[k]);
         if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);
     }
@@ -757,7 +829,8 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     int n = 0;
     double ms = 0.0;
     // the ring-light types share one launch per slot: asking for any of them reads that launch
-    const int key = (effect_type < OALSFX_REVERB && !(debug_flags() & 0x10000)) ? kTimedWaveEffects : effect_type;
+    int key = (effect_type >= 0 && effect_type < OALSFX_REVERB && !(debug_flags() & 0x10000)) ? kTimedWaveEffects : effect_type;
+    if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset; // one general launch for both reverb types
     for (auto& t : b->timed) {
         if (t.type != key) continue;
         if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return 0;

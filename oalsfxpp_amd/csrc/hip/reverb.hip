@@ -138,16 +138,23 @@ __device__ __forceinline__ void scatter(float v[4], float x, float y)
 __device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, int n, float a1, float a2, float& y1, float& y2)
 {
     int i = 0;
-    for (; i + 4 <= n; i += 4) {
-        const float4 u = *reinterpret_cast<const float4*>(row_u + 4 + i);
-        float4 y;
-        y.x = (u.x - (a1 * y1)) - (a2 * y2);
-        y.y = (u.y - (a1 * y.x)) - (a2 * y1);
-        y.z = (u.z - (a1 * y.y)) - (a2 * y.x);
-        y.w = (u.w - (a1 * y.z)) - (a2 * y.y);
-        *reinterpret_cast<float4*>(row_y + 4 + i) = y;
-        y2 = y.z;
-        y1 = y.w;
+    if (n >= 4) {
+        // the next four sums are requested before the current four are worked on: the LDS latency hides behind the
+        // dependent arithmetic instead of adding to it (rows may alias: the request is ahead of the store)
+        float4 u = *reinterpret_cast<const float4*>(row_u + 4);
+        for (; i + 4 <= n; i += 4) {
+            float4 un = u;
+            if (i + 8 <= n) un = *reinterpret_cast<const float4*>(row_u + 8 + i);
+            float4 y;
+            y.x = (u.x - (a1 * y1)) - (a2 * y2);
+            y.y = (u.y - (a1 * y.x)) - (a2 * y1);
+            y.z = (u.z - (a1 * y.y)) - (a2 * y.x);
+            y.w = (u.w - (a1 * y.z)) - (a2 * y.y);
+            *reinterpret_cast<float4*>(row_y + 4 + i) = y;
+            y2 = y.z;
+            y1 = y.w;
+            u = un;
+        }
     }
     for (; i < n; ++i) {
         const float y = (row_u[4 + i] - (a1 * y1)) - (a2 * y2);
@@ -161,9 +168,11 @@ __device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, i
 __device__ __forceinline__ void first_order_chain(const float* row_u, float* row_o, int lo, int hi, float c2, float scale, bool scaled, float& prev)
 {
     int i = lo;
-    if ((lo & 3) == 0) {
+    if ((lo & 3) == 0 && lo + 4 <= hi) {
+        float4 u = *reinterpret_cast<const float4*>(row_u + 4 + lo); // one request ahead, as in biquad_chain
         for (; i + 4 <= hi; i += 4) {
-            const float4 u = *reinterpret_cast<const float4*>(row_u + 4 + i);
+            float4 un = u;
+            if (i + 8 <= hi) un = *reinterpret_cast<const float4*>(row_u + 8 + i);
             float4 o;
             o.x = u.x + (c2 * prev);
             o.y = u.y + (c2 * o.x);
@@ -172,6 +181,7 @@ __device__ __forceinline__ void first_order_chain(const float* row_u, float* row
             prev = o.w;
             if (scaled) { o.x = scale * o.x; o.y = scale * o.y; o.z = scale * o.z; o.w = scale * o.w; }
             *reinterpret_cast<float4*>(row_o + 4 + i) = o;
+            u = un;
         }
     }
     for (; i < hi; ++i) {
@@ -208,7 +218,11 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int CH, int NW, bool TL = false>
+// HY ("hybrid" requests): taps between one and two tiles are accepted too; their groups are requested at the top of
+// their own tile instead of one tile ahead.  Chosen per launch by the host from the parameters (a speed hint).
+// MD (implies HY): instances with a modulated late line are accepted: the depth smoother (a serial lerp chain) runs on
+// lane 0 of each wavefront one tile ahead, the per-sample delays shift the late-line requests.
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const int v_fade = S.fade_count;
     const float v_modf = S.mod_filter;
     const int v_offset = S.offset;
+    const int v_modidx = S.mod_index, v_modrange = S.mod_range;
     const int v_tap = (&S.cur_early_tap[0])[min(lane, 23)];
     const int v_ring_off = PG.ring_off[min(lane >> 2, 4)], v_ring_len = PG.ring_len[min(lane >> 2, 4)];
     const int v_ring_len5 = PG.ring_len[min(lane, 4)];
@@ -274,18 +289,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const float v_gaux = SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
 
     // ---- is this instance in its steady state for the whole buffer? ----
+    unsigned late_mask = 0; // hybrid build: tap groups requested in their own tile
     bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
-              (P.mod_depth == 0.0F) && (v_modf == 0.0F);
+              (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
+    const bool mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
     const float g_cur = v_gcur;
     {
         // the last chunk of the buffer has the smallest ramp counter, hence the largest step: no ramp there, no ramp anywhere
         const int last_chunk = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
         const float step = (v_gtgt - g_cur) * (1.0F / static_cast<float>(last_chunk));
         if (__ballot(q_valid && fabsf(step) > FLT_EPSILON) != 0ULL) go = false;
-        // every tap at least two tiles away from its write position (late taps: from the late feed position)
+        // every tap at least two tiles away from its write position (late taps: from the late feed position); the hybrid
+        // build accepts one tile and requests the groups that are closer than two at the top of their own tile
         const unsigned tp = (lane < 24) ? 4u * static_cast<unsigned>(v_tap) : 0xFFFFFFFFu;
-        const unsigned need = 512u + ((lane >> 2) == 3 ? 4u * static_cast<unsigned>(P.late_feed_tap) : 0u);
-        if (__ballot(tp >= need) != ~0ULL) go = false;
+        unsigned feed4 = (lane >> 2) == 3 ? 4u * static_cast<unsigned>(P.late_feed_tap) : 0u;
+        // a modulated late line reads up to |depth| samples closer (the smoother moves monotonically towards the depth)
+        if (MD && (lane >> 2) == 5) feed4 = 4u * (1u + static_cast<unsigned>(fmaxf(fabsf(P.mod_depth), fabsf(v_modf))));
+        if (__ballot(tp >= (HY ? 256u : 512u) + feed4) != ~0ULL) go = false;
+        if (HY) {
+            const unsigned long long close = __ballot(tp < 512u + feed4);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
+        }
     }
     if (lane == 0) {
         go_all[wib] = go ? 1 : 0;
@@ -341,18 +366,42 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // Software pipeline: inputs of tile k+1 are requested before tile k is computed (every tap is >= 2 tiles away).
     v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
     float n_in0 = 0.0F, n_in1 = 0.0F;
+    auto load4 = [&](unsigned t4x, int group, int r) -> v4f {
+        const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+        const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+        const unsigned bm = utu[ut::BMASK + r];
+        v4f v;
+        v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
+        v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
+        v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
+        v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
+        return v;
+    };
+    // modulated late line (reference calc_modulation_delays, src/oalsfxpp.cpp:7443-7470): delay of this lane's sample in
+    // the tile after the ones already prepared; the smoother's chain is strictly sequential, tile after tile
+    float* modrow = utf + ut::SIZE;
+    float mod_f = v_modf;
+    int mod_tiles = 0;
+    auto next_mod_delays = [&]() -> int {
+        if (lane == 0) {
+            float r = mod_f;
+            const float depth = P.mod_depth, coeff = P.mod_coeff;
+            for (int i = 0; i < 64; ++i) {
+                r = lerpf(r, depth, coeff);
+                modrow[i] = r;
+            }
+        }
+        wave_sync();
+        const float fv = modrow[lane];
+        mod_f = modrow[63];
+        wave_sync();
+        int index = (v_modidx + (mod_tiles << 6) + lane) % v_modrange;
+        mod_tiles += 1;
+        const float sinus = glibc_sinf(6.28318530717958647692F * index / v_modrange);
+        return lround_away(fv * sinus);
+    };
+    int md_next = 0, md_cur = 0;
     auto issue_loads = [&](unsigned t4x, int posx) {
-        auto load4 = [&](int group, int r) -> v4f {
-            const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
-            const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
-            const unsigned bm = utu[ut::BMASK + r];
-            v4f v;
-            v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
-            v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
-            v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
-            v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
-            return v;
-        };
         const int px = min(posx, frames - 1);
         if (CH == 2) {
             const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
@@ -360,12 +409,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         } else {
             n_in0 = src[px];
         }
-        n_e = load4(0, OALSFX_RV_MAIN);
-        n_a = load4(1, OALSFX_RV_EARLY_AP);
-        n_el = load4(2, OALSFX_RV_EARLY_LINE);
-        n_lt = load4(3, OALSFX_RV_MAIN);
-        n_la = load4(4, OALSFX_RV_LATE_AP);
-        n_ll = load4(5, OALSFX_RV_LATE_LINE);
+        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN);
+        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
+        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
+        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN);
+        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
+        if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE);
     };
     auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
@@ -381,6 +430,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
+    if (MD && go && mod_on) md_next = next_mod_delays();
     if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
     stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
@@ -403,6 +453,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         // ---------------- P1: inputs, A-format, feed-forward half of the first shelf ----------------
         if (go) {
             const float in[2] = {n_in0, n_in1};
+            if (MD) {
+                md_cur = md_next;
+                if (mod_on && tile + 1 < tiles) md_next = next_mod_delays();
+            }
+            if (HY) {
+                // groups with a tap closer than two tiles: requested now, after the previous tile's stores
+                if (late_mask & 1u) p_e = load4(t4, 0, OALSFX_RV_MAIN);
+                if (late_mask & 2u) p_a = load4(t4, 1, OALSFX_RV_EARLY_AP);
+                if (late_mask & 4u) p_el = load4(t4, 2, OALSFX_RV_EARLY_LINE);
+                if (late_mask & 8u) p_lt = load4(t4, 3, OALSFX_RV_MAIN);
+                if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
+                if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
+            }
             if (tile + 1 < tiles) issue_loads(t4 + 256u, pos + 64);
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
             if (!first) {
@@ -610,8 +673,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             S.t60[lane][1][0] = ch[coop::T60O1]; S.t60[lane][1][1] = ch[coop::T60O2];
         }
         if (lane == 0) {
-            S.mod_index = static_cast<int>((static_cast<long long>(S.mod_index) + frames) % S.mod_range);
+            S.mod_index = static_cast<int>((static_cast<long long>(v_modidx) + frames) % v_modrange);
             S.offset = offset + frames;
+            if (MD && mod_on) S.mod_filter = mod_f;
         }
         if (first && lane < CH) send_history_follow(ctx, inst, lane, CH, frames, src);
     }
@@ -640,6 +704,14 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     float* utf = gseq + NQ * 64;                             // uniform table, float view
     unsigned* utu = reinterpret_cast<unsigned*>(utf);        // ... unsigned view
 
+    // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock at its phase boundaries, into the
+    // second half of the timeline buffer
+    int gts_i = 0;
+    auto gstamp = [&]() {
+        if (ctx.timeline && (inst & 63) == 0 && (inst >> 6) < 64 && lane == 0 && gts_i < 96)
+            ctx.timeline[64 * 4 * 96 + (inst >> 6) * 96 + gts_i++] = clock64();
+    };
+    gstamp();
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
@@ -758,6 +830,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const float b2a = 0.288675134595F; // |b2a| entries (reference src/oalsfxpp.cpp:6377-6383), signs applied below
     const float apc = P.ap_feed_coeff, mx = P.mix_x, my = P.mix_y;
 
+    gstamp(); // prologue done
     for (int base = resume; base < frames;) {
         int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
         if (OALSFX_RV_FADE_SAMPLES - fade_count > 0) todo = min(todo, OALSFX_RV_FADE_SAMPLES - fade_count);
@@ -824,6 +897,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
 
             wave_sync(); // ring stores of the previous tile precede the loads below (program order)
 
+            gstamp(); // tile start
             // ---------------- loads that do not depend on this tile ----------------
             float in[CH];   // the frame as the direct send sees it
             float win[CH];  // ... as this slot's auxiliary send sees it (differs only after the send-filter pre-pass)
@@ -866,6 +940,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     if (c < channels) out[c] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
             }
 
+            gstamp(); // requests issued
             // ---------------- input: source frame -> dry mix, B-format send, A-format ----------------
             float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
 #pragma unroll
@@ -890,6 +965,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
             a[2] = 0.0F; a[2] += wet[0] * b2a; a[2] += wet[1] * b2a; a[2] += wet[2] * -b2a; a[2] += wet[3] * -b2a;
             a[3] = 0.0F; a[3] += wet[0] * b2a; a[3] += wet[1] * -b2a; a[3] += wet[2] * b2a; a[3] += wet[3] * -b2a;
 
+            gstamp(); // send mix done
             // ---------------- input shelves (reference src/oalsfxpp.cpp:7867-7879) ----------------
             // group 0: a (lp input), group 1: feed-forward sums, group 2: lp output; then hp: 2 -> 1 -> 0
             if (lane < 4) {
@@ -943,6 +1019,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
             }
             wave_sync();
 
+            gstamp(); // shelves done
             // ---------------- early reflections (reference src/oalsfxpp.cpp:7625-7672) ----------------
             float f[4] = {0.0F, 0.0F, 0.0F, 0.0F};
             for (int sb = 0; sb < L;) {
@@ -993,6 +1070,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
             }
             wave_sync();
 
+            gstamp(); // early done
             // ---------------- late reverb (reference src/oalsfxpp.cpp:7735-7794) ----------------
             int md = 0;
             if (mod_active && act) {
@@ -1085,6 +1163,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                 t60_o1b = t60_o1; // the second section's last input is the first section's last output
             }
 
+            gstamp(); // late done
             // ---------------- pan to the outputs with gain ramps (reference src/oalsfxpp.cpp:6142-6166) ----------------
             if (ramp_mask != 0ULL) {
                 if (g_ramp) {
@@ -1194,7 +1273,7 @@ __device__ __noinline__ void reverb_general_call(const KernelCtx* ctx, int slot,
 }
 
 template <int CH>
-__global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1223,27 +1302,35 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 4) void k_reverb(KernelCtx ctx, 
     }
 }
 
-void launch_reverb(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool expect_steady, hipStream_t stream)
+// Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
+// be steady (the kernel decides from the device state) falls back to the general path inside the kernel, out of line.
+void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, hipStream_t stream)
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    const int dbg = flags >> 8; // timing experiments only: 8 = general kernel only
-    KernelCtx general = ctx;
-    if (ctx.channels <= 2 && !(dbg & 8)) {
-        // Steady-state instances run the cooperative tile loop.  If the host expects all of them to be steady this is the
-        // only launch (an instance that turns out not to be falls back to the general path inside it, out of line);
-        // otherwise the others are deferred to the general kernel below, which runs them at full occupancy.
-        const int f = flags | (expect_steady ? 0 : kDeferGeneral);
-        if (ctx.channels == 1) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
-        else if (ctx.timeline) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, true>), grid, block, 0, stream, ctx, slot, list, count, f);
-        else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, ctx, slot, list, count, f);
-        if (expect_steady) return;
-    } else {
-        general.progress = nullptr;
+    KernelCtx c = ctx;
+    c.progress = nullptr;
+    if (c.channels == 1) {
+        if (modulated) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, 0, stream, c, slot, list, count, flags);
+        else if (close_taps) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true>), grid, block, 0, stream, c, slot, list, count, flags);
+        else hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, c, slot, list, count, flags);
     }
-    if (ctx.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, general, slot, list, count, flags);
-    else if (ctx.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, general, slot, list, count, flags);
-    else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, general, slot, list, count, flags);
+    else if (modulated) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, false, true, true>), grid, block, 0, stream, c, slot, list, count, flags);
+    else if (c.timeline) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, true>), grid, block, 0, stream, c, slot, list, count, flags);
+    else if (close_taps) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, false, true>), grid, block, 0, stream, c, slot, list, count, flags);
+    else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, c, slot, list, count, flags);
+}
+
+// Everything else: cross-fades, modulation, gain ramps, taps closer than a tile, partial tiles, more than two channels.
+void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)
+{
+    if (count <= 0) return;
+    const dim3 grid((count + 3) / 4), block(256);
+    KernelCtx c = ctx;
+    c.progress = nullptr;
+    if (c.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, c, slot, list, count, flags);
+    else if (c.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, c, slot, list, count, flags);
+    else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, c, slot, list, count, flags);
 }
 
 } // namespace oalsfx_hip

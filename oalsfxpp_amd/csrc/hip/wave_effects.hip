@@ -43,9 +43,13 @@ __device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a
 {
     float y1 = row[4 + lo - 1], y2 = row[4 + lo - 2];
     int i = lo;
-    if ((lo & 3) == 0) {
+    if ((lo & 3) == 0 && lo + 4 <= hi) {
+        // the next four sums are requested before the current four are worked on: the LDS latency hides behind the
+        // dependent arithmetic instead of adding to it
+        float4 u = *reinterpret_cast<const float4*>(row + 4 + lo);
         for (; i + 4 <= hi; i += 4) {
-            const float4 u = *reinterpret_cast<const float4*>(row + 4 + i);
+            float4 un = u;
+            if (i + 8 <= hi) un = *reinterpret_cast<const float4*>(row + 8 + i);
             float4 y;
             y.x = (u.x - (a1 * y1)) - (a2 * y2);
             y.y = (u.y - (a1 * y.x)) - (a2 * y1);
@@ -54,6 +58,7 @@ __device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a
             *reinterpret_cast<float4*>(row + 4 + i) = y;
             y2 = y.z;
             y1 = y.w;
+            u = un;
         }
     }
     for (; i < hi; ++i) {
@@ -210,12 +215,24 @@ struct CompressorW {
             // the gain follower is a serial min/max recurrence (reference :4385-4400)
             float gc = row[3];
             const float attack = p.attack_rate, release = p.release_rate;
-            for (int i = 0; i < L; ++i) {
-                const float a = row[4 + i];
+            auto follow = [&](float a) {
                 if (a > gc) gc = fminf(gc + attack, a);
                 else if (a < gc) gc = fmaxf(gc - release, a);
-                row[4 + i] = gc;
+                return gc;
+            };
+            int i = 0;
+            if (L >= 4) {
+                float4 a = *reinterpret_cast<const float4*>(row + 4); // one request ahead of the dependent arithmetic
+                for (; i + 4 <= L; i += 4) {
+                    float4 an = a;
+                    if (i + 8 <= L) an = *reinterpret_cast<const float4*>(row + 8 + i);
+                    float4 g;
+                    g.x = follow(a.x); g.y = follow(a.y); g.z = follow(a.z); g.w = follow(a.w);
+                    *reinterpret_cast<float4*>(row + 4 + i) = g;
+                    a = an;
+                }
             }
+            for (; i < L; ++i) row[4 + i] = follow(row[4 + i]);
             row[3] = gc;
         }
         wave_sync();
