@@ -16,7 +16,7 @@ OUT = os.path.join(CSRC, "liboalsfx_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 
 HOST_SOURCES = ["host/props.cpp", "host/panning.cpp", "host/update.cpp", "host/hostabi.cpp", "host/api.cpp"]
-HIP_SOURCES = ["hip/batch.cpp", "hip/reverb.hip", "hip/simple_effects.hip", "hip/wave_effects.hip"]
+HIP_SOURCES = ["hip/batch.cpp", "hip/reverb.hip", "hip/support_kernels.hip", "hip/wave_effects.hip"]
 
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",
           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "hip")]

@@ -77,7 +77,6 @@ struct oalsfx_batch {
     size_t filtered_capacity = 0;                 // floats per send plane
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
-    int* d_progress = nullptr;                    // [n*slots] hand-off between the steady-state and the general reverb kernel
     // Per slot the list is: ring-light types in ascending order (list_offset / list_count per type), then the reverb instances
     // believed steady (reverb, EAX reverb: list_offset / steady_count), then every other reverb instance of both types
     // (general_offset / general_count).  list_count of a reverb type counts all its instances.
@@ -402,15 +401,6 @@ constexpr size_t kTimelineBytes = (64 * 4 + 64) * 96 * sizeof(unsigned long long
 constexpr int kTimedGeneralOffset = 16; // TimedLaunch::type of a reverb type's general-kernel launches
 constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
 
-void launch_type(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
-{
-    const int count = b->list_count[slot][type];
-    if (count == 0) return;
-    if (type == OALSFX_NULL && (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) == 0) return; // a null effect in the middle of the chain does nothing
-    ScopedTiming timing(b, type, stream);
-    oalsfx_hip::launch_simple(type, ctx, slot, b->d_lists + b->list_offset[slot][type], count, flags, stream);
-}
-
 // Can the steady-state kernel be used for this chunk at all?
 bool steady_kernel_usable(const KernelCtx& ctx) { return (ctx.frames & 63) == 0 && ctx.channels <= 2 && !(debug_flags() & 8); }
 
@@ -467,7 +457,6 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.source = b->d_source;
     ctx.source_state = b->d_source_state;
     ctx.mixbuf = b->d_mixbuf;
-    ctx.progress = b->d_progress;
     ctx.timeline = b->d_timeline;
     ctx.slots = b->slots;
     ctx.channels = b->channels;
@@ -514,11 +503,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                     if (!b->hip_ok(hipStreamWaitEvent(gs, b->ev_fork, 0), "hipStreamWaitEvent")) return false;
                 }
                 if (g == 0) {
-                    if (debug_flags() & 0x10000) {
-                        for (int t = 0; t < OALSFX_REVERB; ++t) launch_type(b, t, ctx, s, flags, gs); // first-version kernels, one launch per type
-                    } else {
-                        launch_wave_group(b, ctx, s, flags, gs);
-                    }
+                    launch_wave_group(b, ctx, s, flags, gs);
                 } else if (g == 1) {
                     if (rs > 0) launch_reverb_steady_part(b, OALSFX_REVERB, ctx, s, flags, gs);
                     if (es > 0) launch_reverb_steady_part(b, OALSFX_EAX_REVERB, ctx, s, flags, gs);
@@ -605,8 +590,6 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
-    ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
     if (ok && std::getenv("OALSFX_DEBUG_TIMELINE")) {
@@ -638,7 +621,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
-    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     for (int k = 0; k < kSideStreams; ++k) {
         if (b->side_stream[k]) hipStreamDestroy(b->side_stream[k]);
         if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);
@@ -829,7 +812,7 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     int n = 0;
     double ms = 0.0;
     // the ring-light types share one launch per slot: asking for any of them reads that launch
-    int key = (effect_type >= 0 && effect_type < OALSFX_REVERB && !(debug_flags() & 0x10000)) ? kTimedWaveEffects : effect_type;
+    int key = (effect_type >= 0 && effect_type < OALSFX_REVERB) ? kTimedWaveEffects : effect_type;
     if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset; // one general launch for both reverb types
     for (auto& t : b->timed) {
         if (t.type != key) continue;

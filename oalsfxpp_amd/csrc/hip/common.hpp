@@ -24,7 +24,6 @@ struct KernelCtx {
     const float* wet_src;               // ... as this slot's auxiliary send sees it (== src unless kFiltered)
     float* dst;                         // [instance][frames][channels] interleaved output of this chunk
     float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
-    int* progress;                      // [instance][slots]: frames of this chunk already done by a steady-state kernel
     int slots;
     int channels;
     int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
@@ -38,7 +37,6 @@ enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
     kEax = 4,   // reverb kernels: the list holds EAX reverb instances (second input shelf active)
-    kDeferGeneral = 8, // steady-state reverb kernel: leave non-steady instances to the general kernel launched next
     kFiltered = 16, // the send filters ran as a pre-pass (k_send_filters): src / wet_src are its outputs and the filter
                     // histories are already up to date
 };
@@ -54,8 +52,6 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of a slot in one grid, one wavefront per listed instance (wave_effects.hip)
 void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
-// the first version of those kernels, one lane per instance (simple_effects.hip); kept as a cross-check (OALSFX_DEBUG_FLAGS bit 16)
-void launch_simple(int effect_type, const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,

@@ -679,21 +679,16 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         }
         if (first && lane < CH) send_history_follow(ctx, inst, lane, CH, frames, src);
     }
-    // ---- instances that are not in their steady state ----
-    if (flags & kDeferGeneral) {
-        // a general kernel follows on the same list: tell it how far this instance got
-        if (valid && lane == 0) ctx.progress[sidx] = go ? frames : 0;
-    } else if (valid && !go) {
-        // no second launch was planned (the host expected every instance to be steady): the general path, out of line
-        KernelCtx whole = ctx;
-        whole.progress = nullptr; // nothing of this buffer has been processed for this instance
-        reverb_general_call<CH>(&whole, slot, inst, flags & 0xFF, lds, lane);
+    // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
+    if (valid && !go) {
+        KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
+        reverb_general_call<CH>(&copy, slot, inst, flags & 0xFF, lds, lane);
     }
     stamp(); // state handed back
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
-// partial tiles, any channel count.  Starts at the frame recorded in ctx.progress by a steady-state kernel (if one ran).
+// partial tiles, any channel count.
 template <int CH>
 __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, int slot, int inst, int flags, float* lds, int lane)
 {
@@ -715,9 +710,6 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
-    // frames already done by the steady-state kernel of this launch pair (0 when it did not run)
-    const int resume = ctx.progress ? __builtin_amdgcn_readfirstlane(ctx.progress[sidx]) : 0;
-    if (resume >= frames) return;
     // parameters are read-only for the whole launch: address space 4 (constant) makes every access a scalar load
     typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
     typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
@@ -831,7 +823,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const float apc = P.ap_feed_coeff, mx = P.mix_x, my = P.mix_y;
 
     gstamp(); // prologue done
-    for (int base = resume; base < frames;) {
+    for (int base = 0; base < frames;) {
         int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
         if (OALSFX_RV_FADE_SAMPLES - fade_count > 0) todo = min(todo, OALSFX_RV_FADE_SAMPLES - fade_count);
         const bool faded = fade_count < OALSFX_RV_FADE_SAMPLES; // fade < 1.0
@@ -1278,28 +1270,9 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
     __shared__ __attribute__((aligned(16))) float lds_all[4][Lds<CH>::kFloats];
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    // grid-stride over the list: launched with one wavefront per instance when work is expected, and with a small grid
-    // (each wavefront checks several instances' progress markers) when the host believes every instance is steady
-    const int stride = static_cast<int>(gridDim.x) * 4;
-    const int wave_id = blockIdx.x * 4 + wave_in_block;
-    for (int w0 = wave_id; w0 < count; w0 += 64 * stride) {
-        // lane k looks at the k-th instance of this wavefront's share: all progress markers are fetched in one go
-        const int wk = w0 + lane * stride;
-        bool need = false;
-        int inst_k = 0;
-        if (wk < count) {
-            inst_k = list[wk];
-            need = ctx.progress == nullptr || ctx.progress[static_cast<size_t>(inst_k) * ctx.slots + slot] < ctx.frames;
-        }
-        unsigned long long todo_mask = __ballot(need);
-        while (todo_mask != 0ULL) {
-            const int k = __builtin_ctzll(todo_mask);
-            todo_mask &= todo_mask - 1ULL;
-            const int inst = __shfl(inst_k, k);
-            reverb_general_instance<CH>(ctx, slot, __builtin_amdgcn_readfirstlane(inst), flags, lds_all[wave_in_block], lane);
-            wave_sync();
-        }
-    }
+    const int w = blockIdx.x * 4 + wave_in_block;
+    if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
+    reverb_general_instance<CH>(ctx, slot, __builtin_amdgcn_readfirstlane(list[w]), flags, lds_all[wave_in_block], lane);
 }
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
@@ -1308,8 +1281,7 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    KernelCtx c = ctx;
-    c.progress = nullptr;
+    const KernelCtx& c = ctx;
     if (c.channels == 1) {
         if (modulated) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, 0, stream, c, slot, list, count, flags);
         else if (close_taps) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true>), grid, block, 0, stream, c, slot, list, count, flags);
@@ -1326,8 +1298,7 @@ void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int 
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    KernelCtx c = ctx;
-    c.progress = nullptr;
+    const KernelCtx& c = ctx;
     if (c.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, c, slot, list, count, flags);
     else if (c.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, c, slot, list, count, flags);
     else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, c, slot, list, count, flags);

@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 96)
+raw = np.fromfile(sys.argv[1], dtype=np.uint64)[:64 * 4 * 96].reshape(-1, 4, 96)  # the rest of the file belongs to timeline_general.py
 mhz = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 names = ["P1", "C1", "P2", "C2", "P3", "C3", "P4", "C4", "P5"]
 work = {n: [] for n in names}
