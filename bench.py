@@ -80,6 +80,17 @@ def cpu_baseline(target_seconds=12.0):
     rate = instances * 64 * FRAMES / t
     buffers = max(32, int(target_seconds * rate / (instances * FRAMES)))
     t = o.bench(instances, FRAMES, warm, buffers, threads)
+    # one core, for scale: a short sample of the same workload
+    b1 = max(32, buffers // 8)
+    t1 = o.bench(4, FRAMES, warm, b1, 1)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": round(instances * buffers * FRAMES / t / 1e6, 3),
         "unit": "Msamples/s",
@@ -87,6 +98,8 @@ def cpu_baseline(target_seconds=12.0):
         "kind": "port",
         "sample": f"{instances} EAX-reverb instances x {buffers} buffers of {FRAMES} stereo frames after {warm} warm-up buffers, "
                   f"{threads} threads, oracle/liboracle.so (-O2 -ffp-contract=off), {t:.1f} s",
+        "one_core": round(4 * b1 * FRAMES / t1 / 1e6, 3),
+        "cpu": f"{model}, {os.cpu_count()} logical CPUs on the host",
     }
 
 

@@ -173,6 +173,7 @@ class OracleShadow:
 
     def compare_state(self):
         """Differences between the batch's device state / rings and the oracle's, as strings."""
+        self.sync()  # applied-but-not-yet-mixed changes (e.g. a type change re-creates the state) reach the oracle first
         diffs = []
         for s in range(self.batch.effect_count):
             p, st = self.batch.read_slot(self.instance, s)

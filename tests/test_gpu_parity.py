@@ -222,3 +222,19 @@ def test_randomised_effects_odd_sizes(rate):
     script += [("set", i, 0, random_effect(random.Random(1000 + i), config4_type(i))) for i in range(0, 66, 3)] + [("apply",)]
     script += [("mix", 256), ("mix", 130)]
     run_batch(desc.FMT_STEREO, rate, 1, setups, script)
+
+
+def test_reverb_kernel_hand_over():
+    """One batch whose instances sit on every reverb path at once -- steady-state kernel (defaults), its close-tap build (room:
+    taps of 96 samples), its modulated build (drugged, dizzy), the general kernel (bathroom: taps of 59; psychotic) -- long
+    enough for the host's belief to settle, with property changes that move instances between the paths, a ragged call
+    that forces everything through the general kernel, and a call longer than one 2048-frame chunk."""
+    idx = {"generic": 0, "room": 2, "bathroom": 3, "drugged": 23, "dizzy": 24, "psychotic": 25}
+    order = ["generic", "room", "drugged", "bathroom", "psychotic", "dizzy", "generic", "room", "drugged"]
+    setups = [[(0, preset_effect(idx[k], desc.EAX_REVERB if i % 2 == 0 else desc.REVERB))] for i, k in enumerate(order)]
+    script = [("mix", 256)] * 5
+    script += [("set", 0, 0, preset_effect(idx["drugged"])), ("set", 2, 0, preset_effect(idx["generic"])), ("set", 3, 0, preset_effect(idx["room"])),
+               ("apply",)]
+    script += [("mix", 256)] * 4 + [("mix", 100), ("mix", 256), ("mix", 2048 + 128), ("mix", 64), ("mix", 256)]
+    run_batch(desc.FMT_STEREO, 48000, 1, setups, script)
+    run_batch(desc.FMT_MONO, 44100, 1, setups[:6], script[:12])
