@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 FRAMES = 256
 CHANNELS = 2
 BYTES_PER_FRAME = 208          # 16 B I/O + 24 fp32 delay-line reads + 24 fp32 delay-line writes
+TIMED_EVERY = 4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 METRIC = "Msamples/sec EAX reverb, 256-frame buffers, batch=4096; % HBM roofline"
 METRICS = {
@@ -110,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default 4096; 8192 for config4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="experiment: no HIP events around the launches (roofline fields then use the step time)")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
     ap.add_argument("--preset", type=int, default=-1, help="experiment: every instance uses EFX preset N")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"],
@@ -166,7 +168,9 @@ def main():
     sharding.barrier()
     torch.cuda.synchronize()
 
-    batch.kernel_timing(True)
+    # every 4th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
+    # be part of `value`
+    batch.kernel_timing(0 if args.no_kernel_timing else TIMED_EVERY)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
@@ -192,7 +196,7 @@ def main():
         bytes_per_step = sum(workloads.BYTES_PER_FRAME[workloads.config4_type(rank * n + i)] for i in range(n)) * FRAMES
     else:
         bytes_per_step = BYTES_PER_FRAME * frames_per_launch
-    if workload == "config2":
+    if workload == "config2" and not args.no_kernel_timing:
         # the headline: the dominant kernel alone
         launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
     else:

@@ -90,8 +90,9 @@ int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params
  * value(instance, k) for buffer `buffer_index`, identical to the oracle's generator. */
 int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_index, float* dst_dev, void* hip_stream);
 
-/* ---- HIP-event timing of the dominant kernel, measured on the launch stream.  While enabled, every
- * effect kernel launch is bracketed by events; read() returns the number of launches of `effect_type`
+/* ---- HIP-event timing of the dominant kernel, measured on the launch stream.  enable = 0 switches it off, 1 times every
+ * mix call, k > 1 every k-th (a timed launch costs a few microseconds of dispatch overhead).  The effect kernel launches of a
+ * timed call carry a start / stop event pair; read() returns the number of launches of `effect_type`
  * since enable and their summed duration in milliseconds.  Every effect type of a slot other than the two reverbs shares
  * one launch (k_wave_effects), which any of those types reads.  Reverbs: `effect_type` reads that type's steady-state
  * kernel, `effect_type + 16` the general kernel, which both reverb types share (the groups run side by side). */

@@ -135,8 +135,9 @@ class Batch:
         return p, s
 
     # ---- kernel timing (HIP events on the launch stream) ----
-    def kernel_timing(self, enable=True):
-        self._check(self._lib.oalsfx_batch_kernel_timing(self._h, 1 if enable else 0))
+    def kernel_timing(self, enable=1):
+        """0 / False: off; 1 / True: every mix call carries timing events; k > 1: every k-th call."""
+        self._check(self._lib.oalsfx_batch_kernel_timing(self._h, int(enable)))
 
     def kernel_timing_read(self, effect_type):
         n, ms = C.c_int(0), C.c_double(0.0)

@@ -28,6 +28,8 @@
 using namespace oalsfx_host;
 using oalsfx_hip::KernelCtx;
 
+namespace oalsfx_hip { LaunchEvents g_launch_events; }
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -103,9 +105,19 @@ struct oalsfx_batch {
     const char* error = "";
     std::string error_store;
 
-    bool timing = false;
+    bool timing = false;              // the launches of the current mix call carry events
+    int timing_every = 0;             // 0: off; k: every k-th mix call is timed
+    long long mix_calls = 0;
     std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool; // created when timing is switched on, so that the timed region creates none
 
+    hipEvent_t take_event()
+    {
+        hipEvent_t e = nullptr;
+        if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+        else hipEventCreate(&e);
+        return e;
+    }
     bool fail(const char* msg) { error = msg; return false; }
     bool hip_ok(hipError_t e, const char* what)
     {
@@ -379,20 +391,22 @@ int debug_flags()
     return v;
 }
 
+// Brackets exactly one kernel launch: the events ride on the launch itself (see LaunchEvents).
 struct ScopedTiming {
-    oalsfx_batch* b; hipStream_t stream; TimedLaunch tl{};
-    ScopedTiming(oalsfx_batch* b_, int type, hipStream_t s) : b(b_), stream(s)
+    oalsfx_batch* b; TimedLaunch tl{};
+    ScopedTiming(oalsfx_batch* b_, int type, hipStream_t) : b(b_)
     {
         if (!b->timing) return;
-        hipEventCreate(&tl.start);
-        hipEventCreate(&tl.stop);
+        tl.start = b->take_event();
+        tl.stop = b->take_event();
         tl.type = type;
-        hipEventRecord(tl.start, stream);
+        oalsfx_hip::g_launch_events.start = tl.start;
+        oalsfx_hip::g_launch_events.stop = tl.stop;
     }
     ~ScopedTiming()
     {
         if (!b->timing) return;
-        hipEventRecord(tl.stop, stream);
+        oalsfx_hip::g_launch_events = oalsfx_hip::LaunchEvents{};
         b->timed.push_back(tl);
     }
 };
@@ -439,6 +453,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
 {
     if (!sync_params(b)) return false;
     if (!ensure_mixbuf(b)) return false;
+    b->timing = b->timing_every > 0 && (b->mix_calls++ % b->timing_every) == 0;
     const bool filtered = b->filters_active;
     const int chunk_max = std::min(frames, OALSFX_MAX_CHUNK);
     const size_t plane = static_cast<size_t>(b->n) * chunk_max * b->channels;
@@ -619,6 +634,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
         hipFree(b->d_timeline);
     }
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    for (hipEvent_t e : b->event_pool) hipEventDestroy(e);
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_io_src); hipFree(b->d_io_dst);
@@ -800,9 +816,17 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
 
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable)
 {
-    for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    for (auto& t : b->timed) { b->event_pool.push_back(t.start); b->event_pool.push_back(t.stop); }
     b->timed.clear();
-    b->timing = enable != 0;
+    b->timing_every = enable > 0 ? enable : 0;
+    b->timing = false;
+    b->mix_calls = 0;
+    while (b->timing_every && b->event_pool.size() < 2048) {
+        hipEvent_t e = nullptr;
+        if (!b->hip_ok(hipEventCreate(&e), "hipEventCreate")) return 0;
+        b->event_pool.push_back(e);
+    }
     return 1;
 }
 

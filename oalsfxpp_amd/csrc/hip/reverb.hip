@@ -516,10 +516,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         stamp();
         // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
         if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
             crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
             biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
+            __builtin_amdgcn_s_setprio(0);
         }
         stamp();
         lds_barrier();
@@ -540,9 +542,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         stamp();
             // ---------------- C2 (wave 1) ----------------
             if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
+                __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
                 biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
+                __builtin_amdgcn_s_setprio(0);
             }
             stamp();
         lds_barrier();
@@ -596,10 +600,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         stamp();
         // ---------------- C3 (wave 2): first T60 section ----------------
         if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float prev = cdat[coop::T60O1];
             crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
             first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
             cdat[coop::T60O1] = prev;
+            __builtin_amdgcn_s_setprio(0);
         }
         stamp();
         lds_barrier();
@@ -619,9 +625,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         stamp();
         // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
         if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float prev = cdat[coop::T60O2];
             first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
+            __builtin_amdgcn_s_setprio(0);
         }
         stamp();
         lds_barrier();
@@ -1283,14 +1291,14 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
     if (c.channels == 1) {
-        if (modulated) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, 0, stream, c, slot, list, count, flags);
-        else if (close_taps) hipLaunchKernelGGL((k_reverb_steady_coop<1, 4, false, true>), grid, block, 0, stream, c, slot, list, count, flags);
-        else hipLaunchKernelGGL((k_reverb_steady_coop<1, 4>), grid, block, 0, stream, c, slot, list, count, flags);
+        if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
+        else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true>), grid, block, stream, c, slot, list, count, flags);
+        else OALSFX_LAUNCH((k_reverb_steady_coop<1, 4>), grid, block, stream, c, slot, list, count, flags);
     }
-    else if (modulated) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, false, true, true>), grid, block, 0, stream, c, slot, list, count, flags);
-    else if (c.timeline) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, true>), grid, block, 0, stream, c, slot, list, count, flags);
-    else if (close_taps) hipLaunchKernelGGL((k_reverb_steady_coop<2, 4, false, true>), grid, block, 0, stream, c, slot, list, count, flags);
-    else hipLaunchKernelGGL((k_reverb_steady_coop<2, 4>), grid, block, 0, stream, c, slot, list, count, flags);
+    else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
+    else if (c.timeline) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, true>), grid, block, stream, c, slot, list, count, flags);
+    else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true>), grid, block, stream, c, slot, list, count, flags);
+    else OALSFX_LAUNCH((k_reverb_steady_coop<2, 4>), grid, block, stream, c, slot, list, count, flags);
 }
 
 // Everything else: cross-fades, modulation, gain ramps, taps closer than a tile, partial tiles, more than two channels.
@@ -1299,9 +1307,9 @@ void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int 
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
-    if (c.channels == 1) hipLaunchKernelGGL(k_reverb<1>, grid, block, 0, stream, c, slot, list, count, flags);
-    else if (c.channels == 2) hipLaunchKernelGGL(k_reverb<2>, grid, block, 0, stream, c, slot, list, count, flags);
-    else hipLaunchKernelGGL(k_reverb<8>, grid, block, 0, stream, c, slot, list, count, flags);
+    if (c.channels == 1) OALSFX_LAUNCH(k_reverb<1>, grid, block, stream, c, slot, list, count, flags);
+    else if (c.channels == 2) OALSFX_LAUNCH(k_reverb<2>, grid, block, stream, c, slot, list, count, flags);
+    else OALSFX_LAUNCH(k_reverb<8>, grid, block, stream, c, slot, list, count, flags);
 }
 
 } // namespace oalsfx_hip

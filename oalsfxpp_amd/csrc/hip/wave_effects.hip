@@ -644,9 +644,9 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int co
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    if (ctx.channels == 1) hipLaunchKernelGGL((k_wave_effects<1>), grid, block, 0, stream, ctx, slot, list, count, flags);
-    else if (ctx.channels == 2) hipLaunchKernelGGL((k_wave_effects<2>), grid, block, 0, stream, ctx, slot, list, count, flags);
-    else hipLaunchKernelGGL((k_wave_effects<8>), grid, block, 0, stream, ctx, slot, list, count, flags);
+    if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1>), grid, block, stream, ctx, slot, list, count, flags);
+    else if (ctx.channels == 2) OALSFX_LAUNCH((k_wave_effects<2>), grid, block, stream, ctx, slot, list, count, flags);
+    else OALSFX_LAUNCH((k_wave_effects<8>), grid, block, stream, ctx, slot, list, count, flags);
 }
 
 } // namespace oalsfx_hip
