@@ -63,6 +63,7 @@ struct oalsfx_batch {
     std::vector<int> since_update;                // [n*slots] frames mixed since the slot's last parameter update (capped)
     int unsettled[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // reverb instances per list not yet believed steady
     bool close_taps[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // some reverb of the list has a tap between one and two tiles
+    bool short_taps[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // some reverb of the list has a tap shorter than one tile
     bool modulated[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};  // some reverb of the list has, or had, a modulated late line (sticky:
                                                                // the depth smoother keeps moving long after the depth is set to 0)
     std::vector<int> dirty_list;
@@ -193,8 +194,10 @@ bool reverb_settled(const oalsfx_batch* b, size_t idx)
     if (b->since_update[idx] < kSettleFrames) return false;
     const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
     for (int j = 0; j < 4; ++j) {
-        if (p.early_tap[j] < 64 || p.early_ap_off[j] < 64 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 64 ||
-            p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap + 64)
+        // what the most general build of the steady-state kernel accepts: early / late taps of any length, all-pass
+        // offsets from half a tile, line offsets from one tile
+        if (p.early_tap[j] < 0 || p.early_ap_off[j] < 32 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 32 ||
+            p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap)
             return false;
     }
     return true;
@@ -204,7 +207,7 @@ bool reverb_settled(const oalsfx_batch* b, size_t idx)
 void rescan_close_taps(oalsfx_batch* b)
 {
     for (int s = 0; s < b->slots; ++s)
-        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) b->close_taps[s][t] = false;
+        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) b->close_taps[s][t] = b->short_taps[s][t] = false;
     for (int i = 0; i < b->n; ++i)
         for (int s = 0; s < b->slots; ++s) {
             const oalsfx_slot_params& sp = b->h_params[static_cast<size_t>(i) * b->slots + s];
@@ -214,6 +217,7 @@ void rescan_close_taps(oalsfx_batch* b)
             for (int j = 0; j < 4; ++j)
                 lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
             if (lo >= 64 && lo < 128) b->close_taps[s][sp.type] = true;
+            if (lo < 64) b->short_taps[s][sp.type] = true;
             if (p.mod_depth != 0.0F) b->modulated[s][sp.type] = true;
         }
 }
@@ -423,7 +427,7 @@ void launch_reverb_steady_part(oalsfx_batch* b, int type, const KernelCtx& ctx, 
     const int f = flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | ((debug_flags() & 0xFF) << 8);
     ScopedTiming timing(b, type, stream);
     oalsfx_hip::launch_reverb_steady(ctx, slot, b->d_lists + b->list_offset[slot][type], b->steady_count[slot][type], f, b->close_taps[slot][type],
-                                     b->modulated[slot][type], stream);
+                                     b->modulated[slot][type], b->short_taps[slot][type], stream);
 }
 
 // The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of

@@ -53,8 +53,10 @@ extern LaunchEvents g_launch_events;
 // The host splits every reverb list into the instances it believes steady and the rest (a speed hint: the steady-state
 // kernel still decides per instance from the device state).  close_taps: some listed instance has a tap distance of 64..127
 // samples, which selects the kernel build that can request such groups late; modulated: some listed instance has (or had)
-// a modulated late line, which selects the build that carries the modulation.
-void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, hipStream_t stream);
+// a modulated late line, which selects the build that carries the modulation; short_taps: some listed instance has a tap
+// shorter than one tile, which selects the most general build.
+void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
+                          hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of a slot in one grid, one wavefront per listed instance (wave_effects.hip)
 void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);

@@ -222,7 +222,11 @@ __device__ __forceinline__ void lds_barrier()
 // their own tile instead of one tile ahead.  Chosen per launch by the host from the parameters (a speed hint).
 // MD (implies HY): instances with a modulated late line are accepted: the depth smoother (a serial lerp chain) runs on
 // lane 0 of each wavefront one tile ahead, the per-sample delays shift the late-line requests.
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false>
+// ST (implies HY and MD): taps shorter than a tile where the data they read is produced inside the tile without a loop
+// through the reverb core, or where one extra evaluation settles it: early taps and late taps of any length (their
+// sources, the filtered input and the late feed of an earlier lane, are handed over through LDS rows), and vector
+// all-pass offsets of 32..63 samples (the all-pass outputs of the first lanes are evaluated ahead and handed over).
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const float v_gaux = SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
 
     // ---- is this instance in its steady state for the whole buffer? ----
-    unsigned late_mask = 0; // hybrid build: tap groups requested in their own tile
+    unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
+    unsigned short_mask = 0; // ST build: tap groups with a source inside the tile
     bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
               (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
     const bool mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
@@ -305,7 +310,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         unsigned feed4 = (lane >> 2) == 3 ? 4u * static_cast<unsigned>(P.late_feed_tap) : 0u;
         // a modulated late line reads up to |depth| samples closer (the smoother moves monotonically towards the depth)
         if (MD && (lane >> 2) == 5) feed4 = 4u * (1u + static_cast<unsigned>(fmaxf(fabsf(P.mod_depth), fabsf(v_modf))));
-        if (__ballot(tp >= (HY ? 256u : 512u) + feed4) != ~0ULL) go = false;
+        const int grp = lane >> 2;
+        // shortest distance accepted per group: early / late taps any, all-pass offsets half a tile (ST build only)
+        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 128u : 256u;
+        if (__ballot(tp >= shortest + feed4) != ~0ULL) go = false;
+        if (ST) {
+            const unsigned long long in_tile = __ballot(lane < 24 && tp < 256u + feed4);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) short_mask |= ((in_tile >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
+        }
         if (HY) {
             const unsigned long long close = __ballot(tp < 512u + feed4);
 #pragma unroll
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // modulated late line (reference calc_modulation_delays, src/oalsfxpp.cpp:7443-7470): delay of this lane's sample in
     // the tile after the ones already prepared; the smoother's chain is strictly sequential, tile after tile
     float* modrow = utf + ut::SIZE;
+    auto strow = [&](int k) -> float* { return utf + ut::SIZE + 64 + k * kRow; }; // ST build: 8 hand-over rows
     float mod_f = v_modf;
     int mod_tiles = 0;
     auto next_mod_delays = [&]() -> int {
@@ -563,6 +577,35 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
             const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
             const v4f elc = *reinterpret_cast<const v4f*>(utf + ut::ELCOEF);
+            if (ST && (short_mask & 1u)) {
+                // early taps shorter than the tile read what an earlier lane just wrote to the main delay: the shelves' output
+                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4);
+                const int e0 = static_cast<int>(d.x >> 2), e1 = static_cast<int>(d.y >> 2), e2 = static_cast<int>(d.z >> 2), e3 = static_cast<int>(d.w >> 2);
+                if (lane >= e0) p_e.x = row(xg, 0)[4 + lane - e0];
+                if (lane >= e1) p_e.y = row(xg, 1)[4 + lane - e1];
+                if (lane >= e2) p_e.z = row(xg, 2)[4 + lane - e2];
+                if (lane >= e3) p_e.w = row(xg, 3)[4 + lane - e3];
+            }
+            if (ST && (short_mask & 2u)) {
+                // all-pass offsets of 32..63 samples: the first lanes (sources in earlier tiles) are evaluated ahead, the others
+                // take the all-pass ring values those lanes produce
+                const v2f pf01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
+                const v2f pf23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
+                const v2f pv01 = v2f{p_a.x, p_a.y} - (ac * pf01);
+                const v2f pv23 = v2f{p_a.z, p_a.w} - (ac * pf23);
+                v2f pg01 = pf01 + (ac * pv01);
+                v2f pg23 = pf23 + (ac * pv23);
+                scatter2(pg01, pg23, sx, sy);
+                strow(0)[4 + lane] = pg01.x; strow(1)[4 + lane] = pg01.y; strow(2)[4 + lane] = pg23.x; strow(3)[4 + lane] = pg23.y;
+                wave_sync();
+                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4);
+                const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
+                if (lane >= o0x) p_a.x = strow(0)[4 + lane - o0x];
+                if (lane >= o1x) p_a.y = strow(1)[4 + lane - o1x];
+                if (lane >= o2x) p_a.z = strow(2)[4 + lane - o2x];
+                if (lane >= o3x) p_a.w = strow(3)[4 + lane - o3x];
+                wave_sync();
+            }
             const v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
             const v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
             const v2f v01 = v2f{p_a.x, p_a.y} - (ac * f01);
@@ -578,6 +621,19 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                 v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
                 scatter2(r01, r23, sx, sy);
                 store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
+                if (ST && (short_mask & 8u)) {
+                    // late taps closer than a tile to the late feed read what an earlier lane just fed
+                    strow(4)[4 + lane] = r01.x; strow(5)[4 + lane] = r01.y; strow(6)[4 + lane] = r23.x; strow(7)[4 + lane] = r23.y;
+                    wave_sync();
+                    const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 12);
+                    const unsigned f4 = utu[ut::FEED4];
+                    const int l0 = static_cast<int>((d.x - f4) >> 2), l1 = static_cast<int>((d.y - f4) >> 2), l2 = static_cast<int>((d.z - f4) >> 2),
+                              l3 = static_cast<int>((d.w - f4) >> 2);
+                    if (lane >= l0) p_lt.x = strow(4)[4 + lane - l0];
+                    if (lane >= l1) p_lt.y = strow(5)[4 + lane - l1];
+                    if (lane >= l2) p_lt.z = strow(6)[4 + lane - l2];
+                    if (lane >= l3) p_lt.w = strow(7)[4 + lane - l3];
+                }
             }
             const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
             const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
@@ -638,6 +694,22 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         if (go) {
             const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
             const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
+            if (ST && (short_mask & 16u)) {
+                // late all-pass offsets of 32..63 samples, as for the early all-pass
+                const v2f pl01 = v2f{p_la.x, p_la.y} - (ac * i01);
+                const v2f pl23 = v2f{p_la.z, p_la.w} - (ac * i23);
+                v2f pq01 = i01 + (ac * pl01), pq23 = i23 + (ac * pl23);
+                scatter2(pq01, pq23, sx, sy);
+                strow(0)[4 + lane] = pq01.x; strow(1)[4 + lane] = pq01.y; strow(2)[4 + lane] = pq23.x; strow(3)[4 + lane] = pq23.y;
+                wave_sync();
+                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 16);
+                const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
+                if (lane >= o0x) p_la.x = strow(0)[4 + lane - o0x];
+                if (lane >= o1x) p_la.y = strow(1)[4 + lane - o1x];
+                if (lane >= o2x) p_la.z = strow(2)[4 + lane - o2x];
+                if (lane >= o3x) p_la.w = strow(3)[4 + lane - o3x];
+                wave_sync();
+            }
             const v2f l01 = v2f{p_la.x, p_la.y} - (ac * i01);
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
             v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
@@ -1285,16 +1357,19 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
 // be steady (the kernel decides from the device state) falls back to the general path inside the kernel, out of line.
-void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, hipStream_t stream)
+void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
+                          hipStream_t stream)
 {
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
     if (c.channels == 1) {
-        if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
+        if (short_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
         else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true>), grid, block, stream, c, slot, list, count, flags);
         else OALSFX_LAUNCH((k_reverb_steady_coop<1, 4>), grid, block, stream, c, slot, list, count, flags);
     }
+    else if (short_taps) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
     else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
     else if (c.timeline) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, true>), grid, block, stream, c, slot, list, count, flags);
     else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true>), grid, block, stream, c, slot, list, count, flags);

@@ -238,3 +238,16 @@ def test_reverb_kernel_hand_over():
     script += [("mix", 256)] * 4 + [("mix", 100), ("mix", 256), ("mix", 2048 + 128), ("mix", 64), ("mix", 256)]
     run_batch(desc.FMT_STEREO, 48000, 1, setups, script)
     run_batch(desc.FMT_MONO, 44100, 1, setups[:6], script[:12])
+
+
+@pytest.mark.parametrize("rate", [44100, 48000])
+def test_short_tap_and_modulated_presets_on_the_steady_kernel(rate):
+    """The presets that need the most general build of the steady-state kernel (taps shorter than a tile, all-pass offsets
+    of half a tile, modulated late line), long enough to stay on it for many tiles, as EAX reverb / stereo and as plain
+    reverb / mono, with calls of 64, 256 and 2048 frames."""
+    short = [1, 3, 25, 59, 87, 95, 97, 98, 99]
+    modulated = [i for i in range(113) if preset_effect(i).props.reverb.modulation_depth != 0.0]
+    picks = sorted(set(short + modulated))
+    script = [("mix", 256)] * 10 + [("mix", 2048), ("mix", 64), ("mix", 64), ("mix", 256)]
+    run_batch(desc.FMT_STEREO, rate, 1, [[(0, preset_effect(i))] for i in picks], script)
+    run_batch(desc.FMT_MONO, rate, 1, [[(0, preset_effect(i, desc.REVERB))] for i in picks], script[:12])
