@@ -94,8 +94,8 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
  * mix call, k > 1 every k-th (a timed launch costs a few microseconds of dispatch overhead).  The effect kernel launches of a
  * timed call carry a start / stop event pair; read() returns the number of launches of `effect_type`
  * since enable and their summed duration in milliseconds.  Every effect type of a slot other than the two reverbs shares
- * one launch (k_wave_effects), which any of those types reads.  Reverbs: `effect_type` reads that type's steady-state
- * kernel, `effect_type + 16` the general kernel, which both reverb types share (the groups run side by side). */
+ * one launch (k_wave_effects), which any of those types reads.  The two reverb types share their launches too: either
+ * type reads the steady-state kernel, type + 16 the general kernel (the groups of a slot run side by side). */
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
 

@@ -195,8 +195,8 @@ bool reverb_settled(const oalsfx_batch* b, size_t idx)
     const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
     for (int j = 0; j < 4; ++j) {
         // what the most general build of the steady-state kernel accepts: early / late taps of any length, all-pass
-        // offsets from half a tile, line offsets from one tile
-        if (p.early_tap[j] < 0 || p.early_ap_off[j] < 32 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 32 ||
+        // offsets from a quarter tile, line offsets from one tile
+        if (p.early_tap[j] < 0 || p.early_ap_off[j] < 16 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 16 ||
             p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap)
             return false;
     }
@@ -422,12 +422,15 @@ constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch 
 // Can the steady-state kernel be used for this chunk at all?
 bool steady_kernel_usable(const KernelCtx& ctx) { return (ctx.frames & 63) == 0 && ctx.channels <= 2 && !(debug_flags() & 8); }
 
-void launch_reverb_steady_part(oalsfx_batch* b, int type, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+// One steady-state launch for the believed-steady instances of both reverb types (adjacent in the list; the kernel reads
+// the type per instance).
+void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
 {
-    const int f = flags | (type == OALSFX_EAX_REVERB ? oalsfx_hip::kEax : 0) | ((debug_flags() & 0xFF) << 8);
-    ScopedTiming timing(b, type, stream);
-    oalsfx_hip::launch_reverb_steady(ctx, slot, b->d_lists + b->list_offset[slot][type], b->steady_count[slot][type], f, b->close_taps[slot][type],
-                                     b->modulated[slot][type], b->short_taps[slot][type], stream);
+    const int r = OALSFX_REVERB, e = OALSFX_EAX_REVERB;
+    ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
+    oalsfx_hip::launch_reverb_steady(ctx, slot, b->d_lists + b->list_offset[slot][r], b->steady_count[slot][r] + b->steady_count[slot][e],
+                                     flags | ((debug_flags() & 0xFF) << 8), b->close_taps[slot][r] || b->close_taps[slot][e],
+                                     b->modulated[slot][r] || b->modulated[slot][e], b->short_taps[slot][r] || b->short_taps[slot][e], stream);
 }
 
 // The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of
@@ -502,8 +505,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
             int light = 0;
             for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) light += b->list_count[s][t];
-            // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state kernel per reverb type
-            // (one after the other on one stream) and the general reverb kernel
+            // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state reverb kernel and the general
+            // reverb kernel
             const bool use_steady = steady_kernel_usable(ctx);
             const int rs = use_steady ? b->steady_count[s][OALSFX_REVERB] : 0, es = use_steady ? b->steady_count[s][OALSFX_EAX_REVERB] : 0;
             const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
@@ -524,8 +527,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 if (g == 0) {
                     launch_wave_group(b, ctx, s, flags, gs);
                 } else if (g == 1) {
-                    if (rs > 0) launch_reverb_steady_part(b, OALSFX_REVERB, ctx, s, flags, gs);
-                    if (es > 0) launch_reverb_steady_part(b, OALSFX_EAX_REVERB, ctx, s, flags, gs);
+                    launch_reverb_steady_part(b, ctx, s, flags, gs);
                 } else {
                     launch_reverb_general_part(b, !use_steady, ctx, s, flags, gs);
                 }
@@ -841,7 +843,9 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     double ms = 0.0;
     // the ring-light types share one launch per slot: asking for any of them reads that launch
     int key = (effect_type >= 0 && effect_type < OALSFX_REVERB) ? kTimedWaveEffects : effect_type;
-    if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset; // one general launch for both reverb types
+    // the two reverb types share their launches
+    if (key == OALSFX_REVERB) key = OALSFX_EAX_REVERB;
+    if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset;
     for (auto& t : b->timed) {
         if (t.type != key) continue;
         if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return 0;

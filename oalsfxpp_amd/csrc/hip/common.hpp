@@ -37,7 +37,6 @@ struct KernelCtx {
 enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
-    kEax = 4,   // reverb kernels: the list holds EAX reverb instances (second input shelf active)
     kFiltered = 16, // the send filters ran as a pre-pass (k_send_filters): src / wet_src are its outputs and the filter
                     // histories are already up to date
 };

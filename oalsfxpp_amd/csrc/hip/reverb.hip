@@ -223,9 +223,10 @@ __device__ __forceinline__ void lds_barrier()
 // MD (implies HY): instances with a modulated late line are accepted: the depth smoother (a serial lerp chain) runs on
 // lane 0 of each wavefront one tile ahead, the per-sample delays shift the late-line requests.
 // ST (implies HY and MD): taps shorter than a tile where the data they read is produced inside the tile without a loop
-// through the reverb core, or where one extra evaluation settles it: early taps and late taps of any length (their
+// through the reverb core, or where a few extra evaluations settle it: early taps and late taps of any length (their
 // sources, the filtered input and the late feed of an earlier lane, are handed over through LDS rows), and vector
-// all-pass offsets of 32..63 samples (the all-pass outputs of the first lanes are evaluated ahead and handed over).
+// all-pass offsets of 16..63 samples (the all-pass outputs of the first lanes are evaluated ahead, up to three times,
+// and handed over).
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
@@ -241,13 +242,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
     __shared__ float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     __shared__ int go_all[NW];
+    __shared__ int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = blockIdx.x * NW + wib;
     const bool valid = w < count;
     const int lane = threadIdx.x & 63;
     const int frames = ctx.frames;
-    const bool eax = (flags & kEax) != 0;
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
 
@@ -311,8 +312,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         // a modulated late line reads up to |depth| samples closer (the smoother moves monotonically towards the depth)
         if (MD && (lane >> 2) == 5) feed4 = 4u * (1u + static_cast<unsigned>(fmaxf(fabsf(P.mod_depth), fabsf(v_modf))));
         const int grp = lane >> 2;
-        // shortest distance accepted per group: early / late taps any, all-pass offsets half a tile (ST build only)
-        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 128u : 256u;
+        // shortest distance accepted per group: early / late taps any, all-pass offsets a quarter tile (ST build only)
+        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 64u : 256u;
         if (__ballot(tp >= shortest + feed4) != ~0ULL) go = false;
         if (ST) {
             const unsigned long long in_tile = __ballot(lane < 24 && tp < 256u + feed4);
@@ -325,8 +326,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
     }
+    const bool eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
     if (lane == 0) {
         go_all[wib] = go ? 1 : 0;
+        eax_all[wib] = (go && eax) ? 1 : 0;
     }
     stamp(); // [1] descriptors read, steady-state test done
 
@@ -450,9 +453,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     lds_barrier(); // tables, chain data and go flags are in place
     stamp(); // [4]
     bool any_go = false;
+    bool any_eax = false; // the second-shelf phases (and their barriers) exist when some instance of the group needs them
 #pragma unroll
-    for (int k = 0; k < NW; ++k) any_go |= go_all[k] != 0;
+    for (int k = 0; k < NW; ++k) { any_go |= go_all[k] != 0; any_eax |= eax_all[k] != 0; }
     const bool chain_on = (lane < 4 * NW) && go_all[cw] != 0;
+    const bool chain2_on = chain_on && eax_all[cw] != 0;
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
     // put the same phase on the same SIMD
     const int duty = (wib - static_cast<int>(blockIdx.x)) & (NW - 1);
@@ -541,9 +546,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         lds_barrier();
         stamp();
         int xg = 2;
-        if (eax) {
+        if (any_eax) {
             // ---------------- P2: feed-forward half of the second shelf ----------------
-            if (go) {
+            if (go && eax) {
                 const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
                 const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
                 const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         lds_barrier();
         stamp();
             // ---------------- C2 (wave 1) ----------------
-            if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
+            if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain2_on) {
                 __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
                 biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             stamp();
         lds_barrier();
         stamp();
-            xg = 0;
+            if (eax) xg = 0;
         }
         // ---------------- P3: main delay write, early reflections, late taps, T60 first feed-forward ----------------
         v2f e01 = {0, 0}, e23 = {0, 0};
@@ -587,24 +592,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                 if (lane >= e3) p_e.w = row(xg, 3)[4 + lane - e3];
             }
             if (ST && (short_mask & 2u)) {
-                // all-pass offsets of 32..63 samples: the first lanes (sources in earlier tiles) are evaluated ahead, the others
-                // take the all-pass ring values those lanes produce
-                const v2f pf01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
-                const v2f pf23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
-                const v2f pv01 = v2f{p_a.x, p_a.y} - (ac * pf01);
-                const v2f pv23 = v2f{p_a.z, p_a.w} - (ac * pf23);
-                v2f pg01 = pf01 + (ac * pv01);
-                v2f pg23 = pf23 + (ac * pv23);
-                scatter2(pg01, pg23, sx, sy);
-                strow(0)[4 + lane] = pg01.x; strow(1)[4 + lane] = pg01.y; strow(2)[4 + lane] = pg23.x; strow(3)[4 + lane] = pg23.y;
-                wave_sync();
+                // all-pass offsets shorter than the tile: the lanes whose sources lie in earlier tiles are right from the
+                // start; every evaluation ahead of the real one makes the next `shortest offset` lanes right, which then hand
+                // their all-pass ring values to the lanes that read them
                 const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4);
                 const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
-                if (lane >= o0x) p_a.x = strow(0)[4 + lane - o0x];
-                if (lane >= o1x) p_a.y = strow(1)[4 + lane - o1x];
-                if (lane >= o2x) p_a.z = strow(2)[4 + lane - o2x];
-                if (lane >= o3x) p_a.w = strow(3)[4 + lane - o3x];
-                wave_sync();
+                const int ahead = 63 / min(min(o0x, o1x), min(o2x, o3x));
+                const v2f pf01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
+                const v2f pf23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
+                for (int k = 0; k < ahead; ++k) {
+                    const v2f pv01 = v2f{p_a.x, p_a.y} - (ac * pf01);
+                    const v2f pv23 = v2f{p_a.z, p_a.w} - (ac * pf23);
+                    v2f pg01 = pf01 + (ac * pv01);
+                    v2f pg23 = pf23 + (ac * pv23);
+                    scatter2(pg01, pg23, sx, sy);
+                    strow(0)[4 + lane] = pg01.x; strow(1)[4 + lane] = pg01.y; strow(2)[4 + lane] = pg23.x; strow(3)[4 + lane] = pg23.y;
+                    wave_sync();
+                    if (lane >= o0x) p_a.x = strow(0)[4 + lane - o0x];
+                    if (lane >= o1x) p_a.y = strow(1)[4 + lane - o1x];
+                    if (lane >= o2x) p_a.z = strow(2)[4 + lane - o2x];
+                    if (lane >= o3x) p_a.w = strow(3)[4 + lane - o3x];
+                    wave_sync();
+                }
             }
             const v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
             const v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
@@ -695,20 +704,23 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
             const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
             if (ST && (short_mask & 16u)) {
-                // late all-pass offsets of 32..63 samples, as for the early all-pass
-                const v2f pl01 = v2f{p_la.x, p_la.y} - (ac * i01);
-                const v2f pl23 = v2f{p_la.z, p_la.w} - (ac * i23);
-                v2f pq01 = i01 + (ac * pl01), pq23 = i23 + (ac * pl23);
-                scatter2(pq01, pq23, sx, sy);
-                strow(0)[4 + lane] = pq01.x; strow(1)[4 + lane] = pq01.y; strow(2)[4 + lane] = pq23.x; strow(3)[4 + lane] = pq23.y;
-                wave_sync();
+                // late all-pass offsets shorter than the tile, as for the early all-pass
                 const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 16);
                 const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
-                if (lane >= o0x) p_la.x = strow(0)[4 + lane - o0x];
-                if (lane >= o1x) p_la.y = strow(1)[4 + lane - o1x];
-                if (lane >= o2x) p_la.z = strow(2)[4 + lane - o2x];
-                if (lane >= o3x) p_la.w = strow(3)[4 + lane - o3x];
-                wave_sync();
+                const int ahead = 63 / min(min(o0x, o1x), min(o2x, o3x));
+                for (int k = 0; k < ahead; ++k) {
+                    const v2f pl01 = v2f{p_la.x, p_la.y} - (ac * i01);
+                    const v2f pl23 = v2f{p_la.z, p_la.w} - (ac * i23);
+                    v2f pq01 = i01 + (ac * pl01), pq23 = i23 + (ac * pl23);
+                    scatter2(pq01, pq23, sx, sy);
+                    strow(0)[4 + lane] = pq01.x; strow(1)[4 + lane] = pq01.y; strow(2)[4 + lane] = pq23.x; strow(3)[4 + lane] = pq23.y;
+                    wave_sync();
+                    if (lane >= o0x) p_la.x = strow(0)[4 + lane - o0x];
+                    if (lane >= o1x) p_la.y = strow(1)[4 + lane - o1x];
+                    if (lane >= o2x) p_la.z = strow(2)[4 + lane - o2x];
+                    if (lane >= o3x) p_la.w = strow(3)[4 + lane - o3x];
+                    wave_sync();
+                }
             }
             const v2f l01 = v2f{p_la.x, p_la.y} - (ac * i01);
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
