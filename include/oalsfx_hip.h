@@ -92,12 +92,16 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
 
 /* ---- HIP-event timing of the dominant kernel, measured on the launch stream.  enable = 0 switches it off, 1 times every
  * mix call, k > 1 every k-th (a timed launch costs a few microseconds of dispatch overhead).  The effect kernel launches of a
- * timed call carry a start / stop event pair; read() returns the number of launches of `effect_type`
+ * timed call are bracketed by a start / stop event pair; read() returns the number of launches of `effect_type`
  * since enable and their summed duration in milliseconds.  Every effect type of a slot other than the two reverbs shares
  * one launch (k_wave_effects), which any of those types reads.  The two reverb types share their launches too: either
  * type reads the steady-state kernel, type + 16 the general kernel (the groups of a slot run side by side). */
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
+/* What such an event pair measures beyond the kernel: the average elapsed time of `repeats` pairs with nothing between them
+ * on the batch's stream (about 4.4 us on MI355X).  bench.py reports its kernel time with this subtracted, which agrees with
+ * rocprofv3's kernel trace of the same run to 2 %, and keeps the raw figure next to it. */
+int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us);
 
 /* ---- measurement helper: sweeps a scratch buffer of `bytes` with the reverb kernel's access shape (one dword per lane,
  * 256 contiguous bytes per wave instruction), `repeats` launches of k_hbm_sweep, reading (write == 0) or writing.  Used under

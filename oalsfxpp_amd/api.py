@@ -139,6 +139,12 @@ class Batch:
         """0 / False: off; 1 / True: every mix call carries timing events; k > 1: every k-th call."""
         self._check(self._lib.oalsfx_batch_kernel_timing(self._h, int(enable)))
 
+    def event_overhead(self, repeats=100):
+        """Average microseconds an event pair around an empty kernel reads on the batch's stream."""
+        us = C.c_double(0.0)
+        self._check(self._lib.oalsfx_batch_event_overhead(self._h, repeats, C.byref(us)))
+        return us.value
+
     def kernel_timing_read(self, effect_type):
         n, ms = C.c_int(0), C.c_double(0.0)
         self._check(self._lib.oalsfx_batch_kernel_timing_read(self._h, effect_type, C.byref(n), C.byref(ms)))

@@ -28,8 +28,6 @@
 using namespace oalsfx_host;
 using oalsfx_hip::KernelCtx;
 
-namespace oalsfx_hip { LaunchEvents g_launch_events; }
-
 namespace {
 
 thread_local std::string g_last_error;
@@ -395,22 +393,22 @@ int debug_flags()
     return v;
 }
 
-// Brackets exactly one kernel launch: the events ride on the launch itself (see LaunchEvents).
+// Brackets one kernel launch with events recorded on its stream.  (Events attached to the launch itself through
+// hipExtLaunchKernel were tried: they read 5-6 us longer than rocprofv3's kernel trace of the same run, these 1-2 us.)
 struct ScopedTiming {
-    oalsfx_batch* b; TimedLaunch tl{};
-    ScopedTiming(oalsfx_batch* b_, int type, hipStream_t) : b(b_)
+    oalsfx_batch* b; hipStream_t stream; TimedLaunch tl{};
+    ScopedTiming(oalsfx_batch* b_, int type, hipStream_t s) : b(b_), stream(s)
     {
         if (!b->timing) return;
         tl.start = b->take_event();
         tl.stop = b->take_event();
         tl.type = type;
-        oalsfx_hip::g_launch_events.start = tl.start;
-        oalsfx_hip::g_launch_events.stop = tl.stop;
+        hipEventRecord(tl.start, stream);
     }
     ~ScopedTiming()
     {
         if (!b->timing) return;
-        oalsfx_hip::g_launch_events = oalsfx_hip::LaunchEvents{};
+        hipEventRecord(tl.stop, stream);
         b->timed.push_back(tl);
     }
 };
@@ -857,6 +855,27 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
     return 1;
+}
+
+int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)
+{
+    if (repeats <= 0 || !b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    hipEvent_t e0 = b->take_event(), e1 = b->take_event();
+    double total = 0.0;
+    bool ok = true;
+    for (int r = 0; r < repeats && ok; ++r) {
+        oalsfx_hip::launch_null(b->stream); // something ahead in the stream, as in the timed region
+        hipEventRecord(e0, b->stream);
+        hipEventRecord(e1, b->stream);
+        ok = hipEventSynchronize(e1) == hipSuccess;
+        float ms = 0.0F;
+        ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        total += ms;
+    }
+    b->event_pool.push_back(e0);
+    b->event_pool.push_back(e1);
+    if (avg_us) *avg_us = total * 1e3 / repeats;
+    return ok ? 1 : 0;
 }
 
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats)

@@ -7,7 +7,6 @@
 #define OALSFX_HIP_COMMON_HPP
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "oalsfx_desc.h"
@@ -43,11 +42,6 @@ enum : int {
 
 constexpr int kWave = 64;
 
-// Kernel timing: when the batch has timing switched on it parks a start / stop event pair here right before it calls a
-// launcher; the launch then carries them (hipExtLaunchKernel), which costs no extra packets in the stream.
-struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };
-extern LaunchEvents g_launch_events;
-
 // ---- launchers (defined next to their kernels) ----
 // The host splits every reverb list into the instances it believes steady and the rest (a speed hint: the steady-state
 // kernel still decides per instance from the device state).  close_taps: some listed instance has a tap distance of 64..127
@@ -63,14 +57,14 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int co
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
                          hipStream_t stream);
+void launch_null(hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream);
 void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 
 #if defined(__HIPCC__)
 
-#define OALSFX_LAUNCH(kernel, grid, block, stream, ...)                                                                          \
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, oalsfx_hip::g_launch_events.start, oalsfx_hip::g_launch_events.stop, 0, __VA_ARGS__)
+#define OALSFX_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 
 __device__ __forceinline__ bool audible(float g) { return fabsf(g) > OALSFX_SILENCE_GAIN; }
 

@@ -76,6 +76,11 @@ void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, u
     hipLaunchKernelGGL(k_fill_synthetic, dim3((instances + 63) / 64), dim3(64), 0, stream, dst, instances, floats_per_instance, buffer_index);
 }
 
+// ---- an empty kernel: what an event pair around a launch measures beyond the kernel itself ----
+__global__ void k_null() {}
+
+void launch_null(hipStream_t stream) { hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, stream); }
+
 // ---- HBM counter calibration (measurement helper): reads or writes a buffer with the access shape of the reverb
 // kernel's ring traffic: one dword per lane, 256 contiguous bytes per wave instruction.  Run under
 // rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE it gives the factor between counter values and real bytes for this shape.

@@ -41,6 +41,7 @@ SIGNATURES = {
     "oalsfx_batch_fill_synthetic": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]),
     "oalsfx_batch_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "oalsfx_batch_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "oalsfx_batch_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
     "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),
