@@ -389,7 +389,9 @@ bool ensure_mixbuf(oalsfx_batch* b)
 
 int debug_flags()
 {
-    static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0; // timing experiments only
+    // timing experiments only (OALSFX_DEBUG_FLAGS): 8 every reverb through the general kernel, 32 / 64 tap distances rounded
+    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams
+    static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
     return v;
 }
 
@@ -438,7 +440,7 @@ void launch_reverb_general_part(oalsfx_batch* b, bool everything, const KernelCt
     const int offset = everything ? b->list_offset[slot][OALSFX_REVERB] : b->general_offset[slot];
     const int count = b->general_count[slot] + (everything ? b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB] : 0);
     ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
-    oalsfx_hip::launch_reverb_general(ctx, slot, b->d_lists + offset, count, flags | ((debug_flags() & 0xFF) << 8), stream);
+    oalsfx_hip::launch_reverb_general(ctx, slot, b->d_lists + offset, count, flags, stream);
 }
 
 // All ring-light effect types of a slot in one grid: their instance lists are adjacent in d_lists (types in

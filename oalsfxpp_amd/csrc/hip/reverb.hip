@@ -814,7 +814,6 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
     const bool eax = P.is_eax != 0;
-    const int dbg = flags >> 8; // timing experiments only (OALSFX_DEBUG_FLAGS): 1 skip chains, 2 skip ring loads, 4 skip ring stores
 
     GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)slab;
     Ring ring[5];
@@ -1009,7 +1008,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 p_e[j] = p_a[j] = p_el[j] = p_lt[j] = p_ll[j] = p_la[j] = 0.0F;
-                if (act && !(dbg & 2)) {
+                if (act) {
                     if (pre_e) p_e[j] = ld(slab_b, r_main.at(j, t4 - 4u * cur_etap[j]));
                     if (pre_a) p_a[j] = ld(slab_b, r_eap.at(j, t4 - 4u * cur_eap[j]));
                     if (pre_el) p_el[j] = ld(slab_b, r_eline.at(j, t4 - 4u * cur_eline[j]));
@@ -1073,7 +1072,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                 const float* ra = row(0, lane);
                 const float nx1 = ra[4 + L - 2], nx0 = ra[4 + L - 1]; // L == 1: ra[3] is the old newest sample
                 lpx1 = nx1; lpx0 = nx0;
-                if (!(dbg & 1)) biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
+                biquad_chain(row(1, lane), row(2, lane), L, lp_a1, lp_a2, lpy0, lpy1);
             }
             wave_sync();
             float xin[4];
@@ -1088,7 +1087,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                 wave_sync();
                 if (lane < 4) {
                     row(0, lane)[3] = hpy0; row(0, lane)[2] = hpy1;
-                    if (!(dbg & 1)) biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
+                    biquad_chain(row(1, lane), row(0, lane), L, hp_a1, hp_a2, hpy0, hpy1);
                 }
                 wave_sync();
 #pragma unroll
@@ -1099,7 +1098,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
             }
             if (act) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (!(dbg & 4)) st(slab_b, r_main.at(c, t4), xin[c]);
+                for (int c = 0; c < 4; ++c) st(slab_b, r_main.at(c, t4), xin[c]);
             }
             wave_sync();
 
@@ -1124,14 +1123,14 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     }
                     scatter(g, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_eap.at(j, t4), g[j]);
+                    for (int j = 0; j < 4; ++j) st(slab_b, r_eap.at(j, t4), g[j]);
                 }
                 sb += s;
                 wave_sync();
             }
             if (act) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_eline.at(j, t4), f[3 - j]);
+                for (int j = 0; j < 4; ++j) st(slab_b, r_eline.at(j, t4), f[3 - j]);
             }
             wave_sync();
             float early[4];
@@ -1149,7 +1148,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                 scatter(v, mx, my);
                 if (act) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_main.at(j, t4 - 4u * P.late_feed_tap), v[j]);
+                    for (int j = 0; j < 4; ++j) st(slab_b, r_main.at(j, t4 - 4u * P.late_feed_tap), v[j]);
                 }
             }
             wave_sync();
@@ -1207,7 +1206,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     }
                 }
                 wave_sync();
-                if (lane < 4 && !(dbg & 1)) first_order_chain(row(1, lane), row(2, lane), sb, sb + s, t_l2, 1.0F, false, t60_o1);
+                if (lane < 4) first_order_chain(row(1, lane), row(2, lane), sb, sb + s, t_l2, 1.0F, false, t60_o1);
                 wave_sync();
                 if (on) {
 #pragma unroll
@@ -1217,7 +1216,7 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     }
                 }
                 wave_sync();
-                if (lane < 4 && !(dbg & 1)) first_order_chain(row(1, lane), row(1, lane), sb, sb + s, t_h2, t_mid, true, t60_o2);
+                if (lane < 4) first_order_chain(row(1, lane), row(1, lane), sb, sb + s, t_h2, t_mid, true, t60_o2);
                 wave_sync();
                 if (on) {
                     float v[4], g[4];
@@ -1231,13 +1230,13 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     scatter(g, mx, my);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (!(dbg & 4)) st(slab_b, r_lap.at(j, t4), g[j]);
+                        st(slab_b, r_lap.at(j, t4), g[j]);
                         late[j] = v[j];
                     }
                     float r[4] = {v[3], v[2], v[1], v[0]};
                     scatter(r, mx, my);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(dbg & 4)) st(slab_b, r_lline.at(j, t4), r[j]);
+                    for (int j = 0; j < 4; ++j) st(slab_b, r_lline.at(j, t4), r[j]);
                 }
                 sb += s;
                 wave_sync();
