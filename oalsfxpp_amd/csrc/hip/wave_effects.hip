@@ -152,28 +152,35 @@ struct ModDelayW {
         const float in = wet[0];
         const float fb = p.feedback;
         float t[2];
+        // Sample i reads what sample i - d wrote (d == 0: its own input).  Sources before the tile come from the ring in one
+        // round of loads for both sides; sources inside the tile are handed from lane to lane, the lanes whose source is
+        // settled going together.  The tile's 64 new ring values per side are stored once, at the end.
+        int d[2];
+        bool inside[2];
+        float v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
+            const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
+            d[k] = lfo_delay(p, phase);
+            inside[k] = d[k] > 0 && lane - d[k] >= 0; // written by an earlier lane of this tile
+            v[k] = in;
+            if (lane < L && d[k] != 0 && !inside[k]) v[k] = buf[static_cast<unsigned>(o - d[k]) & mask];
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
-            const int d = lfo_delay(p, phase);
-            // Sample i reads what sample i - d wrote (d == 0: its own input).  Sources before the tile come from the
-            // ring in one round of loads; sources inside the tile are handed from lane to lane, the lanes whose source
-            // is settled going together.  The tile's 64 new ring values are stored once, at the end.
-            const bool inside = d > 0 && lane - d >= 0;   // written by an earlier lane of this tile
-            float v = in;
-            if (lane < L && d != 0 && !inside) v = buf[static_cast<unsigned>(o - d) & mask];
-            float val = 0.0F;                              // what this lane's sample leaves in the ring
+            float val = 0.0F; // what this lane's sample leaves in the ring
             t[k] = 0.0F;
             for (int s = 0; s < L;) {
                 const bool pending = lane >= s && lane < L;
-                const bool blocked = pending && inside && lane - d >= s;
+                const bool blocked = pending && inside[k] && lane - d[k] >= s;
                 const unsigned long long nb = __ballot(blocked);
                 const int e = nb ? static_cast<int>(__builtin_ctzll(nb)) : L;
-                const float handed = __shfl(val, inside ? lane - d : lane);
+                const float handed = __shfl(val, inside[k] ? lane - d[k] : lane);
                 if (pending && lane < e) {
-                    if (inside) v = handed;
-                    t[k] = v * fb;
+                    if (inside[k]) v[k] = handed;
+                    t[k] = v[k] * fb;
                     val = in + t[k];
                 }
                 s = e;
@@ -538,30 +545,50 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     Fx fx;
     fx.init(I);
 
+    // the inputs of a tile (source frame, filtered send input, accumulated mix of the earlier slots) do not depend on the effect:
+    // they are requested one tile ahead, so that their latency hides behind the body of the current tile
+    float n_in[CH], n_win[CH], n_mix[CH];
+    auto request = [&](int base) {
+        const int p = base + lane;
+        const bool a = p < frames;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { n_in[c] = 0.0F; n_mix[c] = 0.0F; }
+        if (a) {
+            if (CH == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(p) * 2);
+                n_in[0] = v.x; n_in[CH - 1] = v.y;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < channels) n_in[c] = src[static_cast<size_t>(p) * channels + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) n_win[c] = n_in[c];
+        if (filtered && a) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < channels) n_win[c] = wsrc[static_cast<size_t>(p) * channels + c];
+        }
+        if (!first && a) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < channels) n_mix[c] = mixbuf[c * OALSFX_MAX_CHUNK + p];
+        }
+    };
+    request(0);
     for (int base = 0; base < frames; base += 64) {
         const int L = min(64, frames - base);
         const bool act = lane < L;
         const int pos = base + lane;
         float in[CH], win[CH], out[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { in[c] = 0.0F; out[c] = 0.0F; }
-        if (act) {
-            if (CH == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(pos) * 2);
-                in[0] = v.x; in[CH - 1] = v.y;
-            } else {
+        for (int c = 0; c < CH; ++c) { in[c] = n_in[c]; win[c] = n_win[c]; out[c] = 0.0F; }
+        float mix[CH];
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < channels) in[c] = src[static_cast<size_t>(pos) * channels + c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) win[c] = in[c];
-        if (filtered && act) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < channels) win[c] = wsrc[static_cast<size_t>(pos) * channels + c];
-        }
+        for (int c = 0; c < CH; ++c) mix[c] = n_mix[c];
+        if (base + 64 < frames) request(base + 64);
+        __builtin_amdgcn_sched_barrier(0); // keep the requests up here
         float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -581,10 +608,9 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
                 }
             }
         }
-        if (!first && act) {
+        if (!first) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < channels) out[c] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
+            for (int c = 0; c < CH; ++c) out[c] = mix[c];
         }
 
         fx.template tile<CH>(I, wet, out, L);
