@@ -453,7 +453,15 @@ void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     for (int t = first_type; t < OALSFX_REVERB; ++t) count += b->list_count[slot][t];
     if (count == 0) return;
     ScopedTiming timing(b, kTimedWaveEffects, stream);
-    oalsfx_hip::launch_wave_effects(ctx, slot, b->d_lists + b->list_offset[slot][first_type], count, flags, stream);
+    oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, flags, stream);
+}
+
+// Number of consecutive slots from `slot` on that hold no reverb at all: such a run is one fused launch over every instance.
+int reverb_free_run(const oalsfx_batch* b, int slot)
+{
+    int n = 0;
+    while (slot + n < b->slots && b->list_count[slot + n][OALSFX_REVERB] + b->list_count[slot + n][OALSFX_EAX_REVERB] == 0) ++n;
+    return n;
 }
 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
@@ -498,10 +506,24 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             ctx.src_stride = ctx.io_stride;
             ctx.src = chunk_src;
         }
+        ctx.wet_plane = filtered ? static_cast<long long>(b->filtered_capacity) : 0;
         for (int s = 0; s < b->slots; ++s) {
+            ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
+            const int run = reverb_free_run(b, s);
+            if (run >= 2) {
+                // slots s .. s+run-1 hold ring-light effects (or nothing) for every instance: one launch, one wavefront per
+                // instance, the slots in order inside it; the slot's list in type order lists every instance exactly once
+                const int run_flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s + run == b->slots ? oalsfx_hip::kLast : 0) |
+                                      (filtered ? oalsfx_hip::kFiltered : 0);
+                {
+                    ScopedTiming timing(b, kTimedWaveEffects, stream);
+                    oalsfx_hip::launch_wave_effects(ctx, s, run, b->d_lists + b->list_offset[s][OALSFX_NULL], b->n, run_flags, stream);
+                }
+                s += run - 1;
+                continue;
+            }
             const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0) |
                               (filtered ? oalsfx_hip::kFiltered : 0);
-            ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
             const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
             int light = 0;
             for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) light += b->list_count[s][t];

@@ -22,6 +22,7 @@ struct KernelCtx {
     oalsfx_source_state* source_state;  // [instance]: histories of the send filters
     const float* src;                   // [instance][frames][channels] interleaved input of this chunk as the direct send sees it
     const float* wet_src;               // ... as this slot's auxiliary send sees it (== src unless kFiltered)
+    long long wet_plane;                // floats between the wet_src planes of consecutive slots (0 unless kFiltered)
     float* dst;                         // [instance][frames][channels] interleaved output of this chunk
     float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
     int slots;
@@ -51,8 +52,8 @@ constexpr int kWave = 64;
 void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
                           hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
-// every ring-light effect type of a slot in one grid, one wavefront per listed instance (wave_effects.hip)
-void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
+// every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
+void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, int flags, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,

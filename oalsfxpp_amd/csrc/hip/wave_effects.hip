@@ -639,9 +639,11 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
 
 } // namespace
 
-// One wavefront per listed instance, any mix of the ring-light effect types.
+// One wavefront per listed instance, any mix of the ring-light effect types, for `slot_count` consecutive slots starting at
+// `slot`: the host fuses runs of slots that hold no reverb at all, so that an instance's chorus -> flanger -> echo chain
+// is one launch (the slots still accumulate in order, through mixbuf, by the same wavefront).
 template <int CH>
-__global__ __launch_bounds__(256) void k_wave_effects(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__global__ __launch_bounds__(256) void k_wave_effects(KernelCtx ctx, int slot, int slot_count, const int* __restrict__ list, int count, int flags)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[4][kLdsFloats];
     const int lane = threadIdx.x & 63;
@@ -650,29 +652,37 @@ __global__ __launch_bounds__(256) void k_wave_effects(KernelCtx ctx, int slot, c
     if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     float* lds = lds_all[wib];
-    const int type = __builtin_amdgcn_readfirstlane(ctx.params[static_cast<size_t>(inst) * ctx.slots + slot].type);
-    switch (type) {
-    case OALSFX_NULL: wave_instance<CH, NullW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_CHORUS:
-    case OALSFX_FLANGER: wave_instance<CH, ModDelayW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_COMPRESSOR: wave_instance<CH, CompressorW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_DEDICATED_DIALOG:
-    case OALSFX_DEDICATED_LFE: wave_instance<CH, DedicatedW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_DISTORTION: wave_instance<CH, DistortionW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_ECHO: wave_instance<CH, EchoW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_EQUALIZER: wave_instance<CH, EqualizerW>(ctx, slot, inst, flags, lds, lane); break;
-    case OALSFX_RING_MODULATOR: wave_instance<CH, RingModW>(ctx, slot, inst, flags, lds, lane); break;
-    default: break;
+    for (int sl = slot; sl < slot + slot_count; ++sl) {
+        const int f = (flags & kFiltered) | ((flags & kFirst) && sl == slot ? kFirst : 0) | ((flags & kLast) && sl == slot + slot_count - 1 ? kLast : 0);
+        const int type = __builtin_amdgcn_readfirstlane(ctx.params[static_cast<size_t>(inst) * ctx.slots + sl].type);
+        KernelCtx c = ctx;
+        c.wet_src = ctx.wet_src + static_cast<size_t>(sl - slot) * ctx.wet_plane;
+        switch (type) {
+        case OALSFX_NULL:
+            if (f & (kFirst | kLast)) wave_instance<CH, NullW>(c, sl, inst, f, lds, lane); // a null effect in the middle does nothing
+            break;
+        case OALSFX_CHORUS:
+        case OALSFX_FLANGER: wave_instance<CH, ModDelayW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_COMPRESSOR: wave_instance<CH, CompressorW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_DEDICATED_DIALOG:
+        case OALSFX_DEDICATED_LFE: wave_instance<CH, DedicatedW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_DISTORTION: wave_instance<CH, DistortionW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_ECHO: wave_instance<CH, EchoW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_EQUALIZER: wave_instance<CH, EqualizerW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_RING_MODULATOR: wave_instance<CH, RingModW>(c, sl, inst, f, lds, lane); break;
+        default: break;
+        }
+        wave_sync(); // the next slot of this instance reads the mix this one just wrote (same wavefront, program order)
     }
 }
 
-void launch_wave_effects(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)
+void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, int flags, hipStream_t stream)
 {
-    if (count <= 0) return;
+    if (count <= 0 || slot_count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
-    if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1>), grid, block, stream, ctx, slot, list, count, flags);
-    else if (ctx.channels == 2) OALSFX_LAUNCH((k_wave_effects<2>), grid, block, stream, ctx, slot, list, count, flags);
-    else OALSFX_LAUNCH((k_wave_effects<8>), grid, block, stream, ctx, slot, list, count, flags);
+    if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1>), grid, block, stream, ctx, slot, slot_count, list, count, flags);
+    else if (ctx.channels == 2) OALSFX_LAUNCH((k_wave_effects<2>), grid, block, stream, ctx, slot, slot_count, list, count, flags);
+    else OALSFX_LAUNCH((k_wave_effects<8>), grid, block, stream, ctx, slot, slot_count, list, count, flags);
 }
 
 } // namespace oalsfx_hip

@@ -251,3 +251,18 @@ def test_short_tap_and_modulated_presets_on_the_steady_kernel(rate):
     script = [("mix", 256)] * 10 + [("mix", 2048), ("mix", 64), ("mix", 64), ("mix", 256)]
     run_batch(desc.FMT_STEREO, rate, 1, [[(0, preset_effect(i))] for i in picks], script)
     run_batch(desc.FMT_MONO, rate, 1, [[(0, preset_effect(i, desc.REVERB))] for i in picks], script[:12])
+
+
+def test_fused_slot_run_with_send_filters_and_nulls():
+    """Slots without any reverb are fused into one launch per run (one wavefront walks an instance's slots in order): with
+    send filters on (every slot reads its own filtered plane), null slots inside and at the ends of the run, a reverb slot
+    after the run, and a type change that breaks the run up."""
+    a = [(0, E(desc.CHORUS)), (1, E(desc.ECHO)), (2, E(desc.EQUALIZER)), (3, E(desc.EAX_REVERB))]
+    bb = [(0, E(desc.NULL)), (1, E(desc.DISTORTION)), (2, E(desc.NULL)), (3, E(desc.REVERB))]
+    c = [(0, E(desc.RING_MODULATOR)), (1, E(desc.NULL)), (2, E(desc.COMPRESSOR)), (3, E(desc.NULL))]
+    script = [("mix", 256), ("mix", 100),
+              ("send", 0, -1, 0.9, 0.5, 1.0), ("send", 0, 1, 1.0, 0.3, 0.6), ("send", 1, 1, 0.8, 1.0, 0.4), ("send", 2, 0, 1.0, 0.7, 0.7),
+              ("send", 2, 2, 0.5, 0.2, 1.0), ("apply",), ("mix", 256), ("mix", 2100),
+              ("set", 0, 1, E(desc.REVERB)), ("apply",), ("mix", 256), ("mix", 256)]
+    run_batch(desc.FMT_STEREO, 48000, 4, [a, bb, c, a], script)
+    run_batch(desc.FMT_QUAD, 44100, 3, [x[:3] for x in (a, bb, c)], script[:10])
