@@ -359,9 +359,13 @@ struct RingModW {
 // Row 0 the filter input, row 1 its output.  tap1 <= tap2, so sub-blocks of min(64, tap1) samples read settled data only.
 struct EchoW {
     int offset;
+    float n_t1, n_t2;   // taps of the next tile, requested one tile ahead when both taps are at least two tiles long
+    bool have_next;
     __device__ void init(const Inst& I)
     {
         offset = I.ss->u.echo.offset;
+        n_t1 = n_t2 = 0.0F;
+        have_next = false;
         if (I.lane == 0) load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
         wave_sync();
     }
@@ -379,9 +383,17 @@ struct EchoW {
         // taps whose source lies before the tile: one round of ring loads
         const bool in1 = p.tap1 > 0 && lane - p.tap1 >= 0, in2 = p.tap2 > 0 && lane - p.tap2 >= 0;
         float t1 = 0.0F, t2 = 0.0F;
-        if (lane < L) {
+        if (have_next) {
+            t1 = n_t1; t2 = n_t2;
+        } else if (lane < L) {
             if (!in1) t1 = I.ring[static_cast<unsigned>(o - p.tap1) & mask];
             if (!in2) t2 = I.ring[static_cast<unsigned>(o - p.tap2) & mask];
+        }
+        // the next tile's taps lie before this tile's writes when both are at least two tiles long: request them now
+        have_next = L == 64 && p.tap1 >= 128 && p.tap2 >= 128;
+        if (have_next) {
+            n_t1 = I.ring[static_cast<unsigned>(o + 64 - p.tap1) & mask];
+            n_t2 = I.ring[static_cast<unsigned>(o + 64 - p.tap2) & mask];
         }
         for (int s = 0; s < L; s += block) {
             const int e = min(L, s + block);
@@ -524,7 +536,9 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
-    const oalsfx_source_params& SRC = ctx.source[inst];
+    // send gains through the constant address space: scalar loads, hoisted out of the tile loop
+    typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
+    ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
     const bool filtered = (flags & kFiltered) != 0;
@@ -542,8 +556,16 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     I.lane = lane;
     I.channels = channels;
 
+    // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock around the parts of slot 0's tiles
+    int ts_i = 0;
+    auto stamp = [&]() {
+        if (ctx.timeline && slot == 0 && (inst & 63) == 0 && (inst >> 6) < 64 && lane == 0 && ts_i < 96)
+            ctx.timeline[64 * 4 * 96 + (inst >> 6) * 96 + ts_i++] = clock64();
+    };
+    stamp();
     Fx fx;
     fx.init(I);
+    stamp();
 
     // the inputs of a tile (source frame, filtered send input, accumulated mix of the earlier slots) do not depend on the effect:
     // they are requested one tile ahead, so that their latency hides behind the body of the current tile
@@ -612,8 +634,9 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
 #pragma unroll
             for (int c = 0; c < CH; ++c) out[c] = mix[c];
         }
-
+        stamp();
         fx.template tile<CH>(I, wet, out, L);
+        stamp();
 
         if (act) {
             if (last) {
