@@ -266,3 +266,34 @@ def test_fused_slot_run_with_send_filters_and_nulls():
               ("set", 0, 1, E(desc.REVERB)), ("apply",), ("mix", 256), ("mix", 256)]
     run_batch(desc.FMT_STEREO, 48000, 4, [a, bb, c, a], script)
     run_batch(desc.FMT_QUAD, 44100, 3, [x[:3] for x in (a, bb, c)], script[:10])
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_scripts(seed):
+    """Random call sequences against the oracle: random effect types and properties per slot (nulls included), property and
+    type changes, send filters switched on and off, ragged call sizes, several channel formats and rates."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect
+    rng = random.Random(1234 + seed)
+    fmt = rng.choice([desc.FMT_MONO, desc.FMT_STEREO, desc.FMT_STEREO, desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_7POINT1])
+    rate = rng.choice([22050, 44100, 48000, 48000, 96000])
+    slots = rng.randint(1, 4)
+    n = 6
+    types = list(range(12))
+    setups = [[(s, random_effect(rng, rng.choice(types))) for s in range(slots)] for _ in range(n)]
+    script = []
+    for _ in range(14):
+        r = rng.random()
+        if r < 0.55:
+            script.append(("mix", rng.choice([1, 2, 63, 64, 64, 128, 256, 256, 256, 300, 2048 + 17])))
+        elif r < 0.75:
+            script.append(("set", rng.randrange(n), rng.randrange(slots), random_effect(rng, rng.choice(types))))
+            script.append(("apply",))
+        elif r < 0.9:
+            script.append(("send", rng.randrange(n), rng.randint(-1, slots - 1), rng.uniform(0.2, 1.0), rng.choice([1.0, rng.uniform(0.1, 1.0)]),
+                           rng.choice([1.0, rng.uniform(0.1, 1.0)])))
+            script.append(("apply",))
+        else:
+            script.append(("apply",))
+    script += [("mix", 256), ("mix", 256)]
+    run_batch(fmt, rate, slots, setups, script)
