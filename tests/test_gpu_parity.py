@@ -297,3 +297,52 @@ def test_random_scripts(seed):
             script.append(("apply",))
     script += [("mix", 256), ("mix", 256)]
     run_batch(fmt, rate, slots, setups, script)
+
+
+def test_full_size_config2_replicas_and_sample():
+    """BASELINE configs[1] at full size (4096 EAX reverbs, every workgroup of the launch in play).  Size-independent
+    properties: instances fed the same input stay bit-identical to each other, and a sample of instances fed their own
+    input matches the oracle, outputs and state."""
+    n = 4096
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        sample = [0, 1, 3, 4, 255, 256, 1023, 2048, 2049, 4094, 4095]
+        shadows = {i: OracleShadow(b, i) for i in sample}
+        for k in range(6):
+            x = np.empty((n, 256, 2), dtype=np.float32)
+            common = orc.synth(7, k, 512).reshape(256, 2)
+            x[:] = common                     # replicas: everyone hears the same ...
+            for i in sample:
+                x[i] = orc.synth(1000 + i, k, 512).reshape(256, 2)   # ... except the sampled instances
+            y = b.mix(x)
+            for i in sample:
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                assert ok, f"instance {i} buffer {k}: {nbad} samples differ"
+            rest = np.setdiff1d(np.arange(n), sample)
+            ref = y[rest[0]].tobytes()
+            assert all(y[i].tobytes() == ref for i in rest[1:]), f"buffer {k}: replicas diverged"
+        for i in sample:
+            assert not shadows[i].compare_state(), f"instance {i}: state differs"
+
+
+def test_full_size_config4_sample():
+    """BASELINE configs[3] at full size (8192 instances, 11 effect types, randomised properties): two instances of every
+    type against the oracle."""
+    import random
+    from oalsfxpp_amd.workloads import config4_type, random_effect
+    n = 8192
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [random_effect(random.Random(i), config4_type(i)) for i in range(n)])
+        b.apply_changes()
+        sample = list(range(11)) + list(range(8192 - 11, 8192))
+        shadows = {i: OracleShadow(b, i) for i in sample}
+        rng = np.random.default_rng(3)
+        for k in range(5):
+            x = rng.uniform(-1, 1, size=(n, 256, 2)).astype(np.float32)
+            y = b.mix(x)
+            for i in sample:
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                assert ok, f"instance {i} (type {config4_type(i)}) buffer {k}: {nbad} samples differ"
+        for i in sample:
+            assert not shadows[i].compare_state(), f"instance {i}: state differs"
