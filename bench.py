@@ -84,6 +84,18 @@ def cpu_baseline(target_seconds=12.0):
     # one core, for scale: a short sample of the same workload
     b1 = max(32, buffers // 8)
     t1 = o.bench(4, FRAMES, warm, b1, 1)
+    # the same source at -O3 -march=x86-64-v3 with FMA contraction allowed (within 1e-5 of the parity build,
+    # tests/test_oracle_fast.py): the fastest fair scalar CPU figure
+    fast_value = None
+    try:
+        of = orc.Oracle(CHANNELS, 1, fast=True)
+        of.set_source(sp)
+        of.set_slot(0, p, restart=True)
+        bf = max(32, buffers // 2)
+        tf = of.bench(instances, FRAMES, warm, bf, threads)
+        fast_value = round(instances * bf * FRAMES / tf / 1e6, 3)
+    except (FileNotFoundError, OSError):
+        pass
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -100,6 +112,7 @@ def cpu_baseline(target_seconds=12.0):
         "sample": f"{instances} EAX-reverb instances x {buffers} buffers of {FRAMES} stereo frames after {warm} warm-up buffers, "
                   f"{threads} threads, oracle/liboracle.so (-O2 -ffp-contract=off), {t:.1f} s",
         "one_core": round(4 * b1 * FRAMES / t1 / 1e6, 3),
+        "value_o3_x86_64_v3_fma": fast_value,
         "cpu": f"{model}, {os.cpu_count()} logical CPUs on the host",
     }
 

@@ -16,6 +16,7 @@ from oalsfxpp_amd import desc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+_ORACLE_FAST_SO = os.path.join(_HERE, "liboracle_fast.so")  # -O3 -march=x86-64-v3, FMA contraction allowed: cpu_baseline only
 _REF_SO = os.path.join(_HERE, "_ref", "libref.so")
 
 _fp = C.POINTER(C.c_float)
@@ -23,7 +24,7 @@ _fp = C.POINTER(C.c_float)
 
 def build(ref=True):
     """(Re)build the checkers with oracle/Makefile; the reference part is skipped when /root/reference is absent."""
-    targets = ["oracle"] + (["ref"] if ref else [])
+    targets = ["oracle", "fast"] + (["ref"] if ref else [])
     subprocess.run(["make", "-C", _HERE] + targets, check=True, stdout=subprocess.DEVNULL)
 
 
@@ -37,13 +38,14 @@ def _load(path):
     return C.CDLL(path)
 
 
-_oracle = None
+_oracle = {}
 
 
-def oracle_lib():
+def oracle_lib(fast=False):
+    """fast=False: the parity build (bit-identical to the reference); fast=True: the tolerance-checked speed build."""
     global _oracle
-    if _oracle is None:
-        lib = _load(_ORACLE_SO)
+    if fast not in _oracle:
+        lib = _load(_ORACLE_FAST_SO if fast else _ORACLE_SO)
         lib.oracle_create.restype = C.c_void_p
         lib.oracle_create.argtypes = [C.c_int, C.c_int]
         lib.oracle_destroy.argtypes = [C.c_void_p]
@@ -57,8 +59,8 @@ def oracle_lib():
         lib.oracle_synth.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _fp]
         lib.oracle_bench.restype = C.c_double
         lib.oracle_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
-        _oracle = lib
-    return _oracle
+        _oracle[fast] = lib
+    return _oracle[fast]
 
 
 def synth(instance, buffer_index, count):
@@ -71,8 +73,8 @@ def synth(instance, buffer_index, count):
 class Oracle:
     """One instance of the CPU restatement, driven with descriptors from the host update path."""
 
-    def __init__(self, channels, slots):
-        self.lib = oracle_lib()
+    def __init__(self, channels, slots, fast=False):
+        self.lib = oracle_lib(fast)
         self.channels, self.slots = channels, slots
         self.h = C.c_void_p(self.lib.oracle_create(channels, slots))
 
