@@ -102,6 +102,10 @@ struct Inst {
     int channels;
 };
 
+// std::max / std::min as the reference uses them (first argument wins when the comparison is false, NaNs included)
+__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
+
 template <int CH, class G>
 __device__ __forceinline__ void pan(float out[CH], int channels, const G& gains, float v)
 {
@@ -214,7 +218,7 @@ struct CompressorW {
         float amplitude = 1.0F;
         if (p.enabled) {
             amplitude = fabsf(wet[0]);
-            amplitude = fmaxf(amplitude + fabsf(wet[1]), fmaxf(amplitude + fabsf(wet[2]), amplitude + fabsf(wet[3])));
+            amplitude = std_max(amplitude + fabsf(wet[1]), std_max(amplitude + fabsf(wet[2]), amplitude + fabsf(wet[3])));
         }
         row[4 + I.lane] = amplitude;
         wave_sync();
@@ -223,8 +227,8 @@ struct CompressorW {
             float gc = row[3];
             const float attack = p.attack_rate, release = p.release_rate;
             auto follow = [&](float a) {
-                if (a > gc) gc = fminf(gc + attack, a);
-                else if (a < gc) gc = fmaxf(gc - release, a);
+                if (a > gc) gc = std_min(gc + attack, a);
+                else if (a < gc) gc = std_max(gc - release, a);
                 return gc;
             };
             int i = 0;
@@ -243,7 +247,7 @@ struct CompressorW {
             row[3] = gc;
         }
         wave_sync();
-        const float output = 1.0F / fminf(2.0F, fmaxf(0.5F, row[4 + I.lane]));
+        const float output = 1.0F / std_min(2.0F, std_max(0.5F, row[4 + I.lane])); // Math::clamp(gc, 0.5, 2) = min(max_value, max(min_value, gc))
         wave_sync();
 #pragma unroll
         for (int j = 0; j < 4; ++j) pan<CH>(out, I.channels, p.gains[j], wet[j] * output);

@@ -346,3 +346,54 @@ def test_full_size_config4_sample():
                 assert ok, f"instance {i} (type {config4_type(i)}) buffer {k}: {nbad} samples differ"
         for i in sample:
             assert not shadows[i].compare_state(), f"instance {i}: state differs"
+
+
+def test_denormal_signals():
+    """Signals around and below the smallest normal float: the reference runs on x86 without flush-to-zero, and so do the
+    kernels (fp32 denormals are on by default on gfx9); a flush anywhere would show up as a bit difference."""
+    setups = [[(0, E(t))] for t in (desc.EAX_REVERB, desc.REVERB, desc.ECHO, desc.EQUALIZER, desc.CHORUS, desc.DISTORTION, desc.COMPRESSOR,
+                                    desc.RING_MODULATOR)]
+    n = len(setups)
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        for i, eff in enumerate(setups):
+            b.set_effect(0, eff[0][1], first=i, count=1)
+        b.apply_changes()
+        shadows = [OracleShadow(b, i) for i in range(n)]
+        for k, scale in enumerate([1e-36, 1e-37, 1e-38, 3e-39, 1e-40, 1e-42, 0.0, 0.0, 1e-38, 0.0]):
+            x = np.stack([orc.synth(50 + i, k, 512).reshape(256, 2) for i in range(n)]) * np.float32(scale)
+            y = b.mix(x.astype(np.float32))
+            for i in range(n):
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i].astype(np.float32)))
+                assert ok, f"instance {i} buffer {k} (scale {scale}): {nbad} samples differ"
+        for i in range(n):
+            assert not shadows[i].compare_state(), f"instance {i}: state differs"
+
+
+def test_huge_infinite_and_nan_inputs():
+    """Garbage in, the same garbage out: very large samples, infinities and NaNs take the same path through every effect as
+    in the reference (std::min / std::max argument order included); NaN payloads and signs are not compared."""
+    types = (desc.EAX_REVERB, desc.ECHO, desc.EQUALIZER, desc.CHORUS, desc.DISTORTION, desc.COMPRESSOR, desc.RING_MODULATOR, desc.DEDICATED_DIALOG)
+    n = len(types)
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        for i, t in enumerate(types):
+            b.set_effect_type(0, t, first=i, count=1)
+        b.apply_changes()
+        shadows = [OracleShadow(b, i) for i in range(n)]
+        for k in range(6):
+            x = np.stack([orc.synth(80 + i, k, 512).reshape(256, 2) for i in range(n)]).astype(np.float32)
+            if k == 1:
+                x *= np.float32(1e30)
+            if k == 2:
+                x *= np.float32(3e38)
+            if k == 3:
+                x[:, 10, 0] = np.inf
+                x[:, 100, 1] = -np.inf
+            if k == 4:
+                x[:, 5, 1] = np.nan
+            with np.errstate(all="ignore"):
+                y = b.mix(x)
+                for i in range(n):
+                    ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                    assert ok, f"instance {i} (type {types[i]}) buffer {k}: {nbad} samples differ"
+        for i in range(n):
+            assert not shadows[i].compare_state(), f"instance {i}: state differs"
