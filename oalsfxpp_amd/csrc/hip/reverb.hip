@@ -1,30 +1,29 @@
-// Reverb / EAX reverb process kernel for gfx950 (the headline kernel).
+// Reverb / EAX reverb process kernels for gfx950 (the headline path).
 //
-// Replaces ReverbEffectState::do_process and everything under it (reference
-// src/oalsfxpp.cpp:6078-6170, 7358-7903) plus, when this slot is first / last, the dry mix of
-// mix_source (src/oalsfxpp.cpp:2917-2950) and the interleave of write_f32 (src/oalsfxpp.cpp:3414-3431).
+// They replace ReverbEffectState::do_process and everything under it (reference src/oalsfxpp.cpp:6078-6170, 7358-7903)
+// plus, when the slot is first / last, the dry mix of mix_source (src/oalsfxpp.cpp:2917-2950) and the interleave of
+// write_f32 (src/oalsfxpp.cpp:3414-3431).
 //
-// Mapping (MI355X-first):
-//   * one 64-lane wavefront per effect instance; 4 independent wavefronts per 256-thread workgroup,
-//     no workgroup barrier anywhere, so every branch below is wave-uniform (parameters, fade state and
-//     tile sizes are per instance);
-//   * lanes are consecutive sample times of a tile of <= 64 frames; each lane carries the 4-line
-//     A-format vector of its sample in registers, so the scattering matrices are register math;
-//   * every delay ring is stored per line (line j of ring r is one contiguous power-of-two ring), so
-//     a tap read or a ring write of a tile is one contiguous 256-byte wave access;
-//   * in the steady state (no cross-fade) every tap whose delay keeps it outside the tile is loaded at
-//     the top of the tile, before any arithmetic: one HBM round trip per tile, hidden behind the
-//     input-shelf recurrences;
-//   * feedback paths (the two vector all-passes, the modulated late line) are honoured by cutting a
-//     tile into sub-blocks no longer than the shortest positive feedback delay (23+ samples at
-//     48 kHz, so usually the whole tile); a delay of 0 in a feedback ring reads the slot before it is
-//     written (the reference's read-before-write order) and needs no cut;
-//   * the second-order input shelves and the first-order T60 sections are serial recurrences that
-//     must round exactly like the reference: their feed-forward half is evaluated per lane, the
-//     feedback half runs on 4 "chain" lanes (one per line) over the tile via an LDS transpose.
+// Map of this file (design notes in DESIGN.md 3.1):
+//   * helpers shared by both kernels: byte-offset ring addressing, the scattering matrix, the serial halves of the
+//     biquad and first-order sections (one LDS request ahead of the dependent arithmetic);
+//   * k_reverb_steady_coop -- instances in their steady state: a workgroup is four wavefronts = four instances, lanes are
+//     64 consecutive sample times, all ring taps of a tile are requested one tile ahead, and the serial filter
+//     recurrences of the four instances run together on 16 lanes of one wavefront per chain phase.  Builds: plain,
+//     HY (taps of 64..127 samples), MD (modulated late line), ST (taps shorter than a tile);
+//   * reverb_general_instance / k_reverb -- everything else (cross-fades, gain ramps, ragged tiles, more than two
+//     channels, parameter sets outside the steady-state builds): one wavefront per instance, feedback honoured by
+//     cutting a tile into sub-blocks no longer than the shortest positive feedback delay; also the out-of-line fallback
+//     of the steady-state kernel for an instance that turns out not to be steady;
+//   * the launchers.
 //
-// Ordering of ring stores and later tap loads inside one wavefront relies on the hardware executing a
-// wavefront's memory instructions in order; the wavefront-scope fences below only pin the compiler.
+// Common to both: every delay ring is stored per line (line j of ring r is one contiguous power-of-two ring), so a tap
+// read or a ring write of a tile is one contiguous 256-byte wave access; each lane carries the 4-line vector of its
+// sample in registers; recurrences that must round exactly like the reference keep their order (feed-forward half per
+// lane, feedback half on chain lanes over an LDS transpose).
+//
+// Ordering of ring stores and later tap loads inside one wavefront relies on the hardware executing a wavefront's
+// memory instructions in order; the wavefront-scope fences only pin the compiler.
 //
 // Bit-exactness: compiled with -ffp-contract=off; expression association follows the reference.
 #include <float.h>
@@ -195,13 +194,12 @@ __device__ __forceinline__ void first_order_chain(const float* row_u, float* row
 
 
 // =================================================================================================
-// Cooperative steady-state kernel: like k_reverb_steady (one wavefront per instance, 64 sample times per
-// tile, packed arithmetic, prefetched taps), but the serial filter recurrences of the four instances of a
-// workgroup are run together: for every chain phase one wavefront executes the recurrences of all 16
-// (instance, line) pairs on 16 lanes while its siblings wait at a workgroup barrier.  The recurrences are
-// about 70 % of the vector instructions of the per-wave version (4 active lanes each); sharing them cuts
-// that part by four.  A workgroup takes this path only with full 64-frame tiles; an instance that is not
-// in its steady state sits the phases out (empty chain range) and is left to the general kernel.
+// Cooperative steady-state kernel: one wavefront per instance, 64 sample times per tile, packed arithmetic, taps requested
+// a tile ahead; the serial filter recurrences of the four instances of a workgroup are run together: for every chain
+// phase one wavefront executes the recurrences of all 16 (instance, line) pairs on 16 lanes while its siblings wait at a
+// workgroup barrier.  Run per wavefront on 4 lanes those recurrences were about 70 % of the vector instructions; sharing
+// them cuts that part by four.  An instance that is not in its steady state sits the phases out (empty chain range) and
+// takes the general path at the end of the kernel.
 //
 // Barriers are raw s_barrier preceded by s_waitcnt lgkmcnt(0) only: LDS traffic must be complete, global
 // loads (the prefetch of the next tile) and ring stores stay in flight across them.
