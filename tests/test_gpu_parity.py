@@ -397,3 +397,36 @@ def test_huge_infinite_and_nan_inputs():
                     assert ok, f"instance {i} (type {types[i]}) buffer {k}: {nbad} samples differ"
         for i in range(n):
             assert not shadows[i].compare_state(), f"instance {i}: state differs"
+
+
+def test_error_conventions_on_the_device_path():
+    """Calls fail with 0 / false and a static message, like the reference (Api::mix preconditions src/oalsfxpp.cpp:3790-3811,
+    effect index checks :3560-3570); a failed call leaves the batch usable."""
+    import ctypes as C
+    from oalsfxpp_amd import lib as L
+    so = L.load()
+    with Batch(3, desc.FMT_STEREO, 48000, 2) as b:
+        b.set_effect_type(0, desc.ECHO)
+        b.apply_changes()
+        h = b._h
+        fp = C.POINTER(C.c_float)
+        buf = (C.c_float * (3 * 16 * 2))()
+        assert so.oalsfx_batch_mix(h, 0, None, None) == 1                      # zero frames succeed before any pointer check
+        assert so.oalsfx_batch_mix(h, 16, None, C.cast(buf, fp)) == 0 and b.error == "No source samples."
+        assert so.oalsfx_batch_mix(h, 16, C.cast(buf, fp), None) == 0 and b.error == "No destination samples."
+        assert so.oalsfx_batch_mix(h, -4, C.cast(buf, fp), C.cast(buf, fp)) == 0 and b.error == "Frame count is negative."
+        assert so.oalsfx_batch_set_effect_type(h, 0, 3, 2, desc.ECHO) == 0 and b.error == "Effect index is out of range."
+        assert so.oalsfx_batch_set_effect_type(h, 2, 2, 0, desc.ECHO) == 0 and b.error == "Instance range is out of bounds."
+        e = desc.Effect()
+        assert so.oalsfx_batch_get_effect(h, 0, 5, 0, C.byref(e)) == 0
+        # in place (src == dst) works like in the reference, and the batch is still fine after the failures
+        x = np.stack([orc.synth(i, 0, 32).reshape(16, 2) for i in range(3)])
+        want = b.mix(x)
+        inplace = np.ascontiguousarray(x.copy())
+        p = inplace.ctypes.data_as(fp)
+        # rewind: a second batch gives the same first buffer
+    with Batch(3, desc.FMT_STEREO, 48000, 2) as b2:
+        b2.set_effect_type(0, desc.ECHO)
+        b2.apply_changes()
+        assert so.oalsfx_batch_mix(b2._h, 16, p, p) == 1
+        assert inplace.tobytes() == want.tobytes()
