@@ -430,3 +430,33 @@ def test_error_conventions_on_the_device_path():
         b2.apply_changes()
         assert so.oalsfx_batch_mix(b2._h, 16, p, p) == 1
         assert inplace.tobytes() == want.tobytes()
+
+
+def test_two_batches_and_a_caller_stream():
+    """Two batches advanced alternately in one process, one of them through oalsfx_batch_mix_device on a caller-supplied
+    stream with device-resident buffers: each matches the oracle and neither disturbs the other."""
+    import torch
+    n, frames = 5, 256
+    s = torch.cuda.Stream()
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as a, Batch(n, desc.FMT_STEREO, 48000, 2) as b:
+        a.set_effect_type(0, desc.EAX_REVERB)
+        a.apply_changes()
+        b.set_effect_type(0, desc.FLANGER)
+        b.set_effect(1, preset_effect(40))
+        b.apply_changes()
+        sa, sb = OracleShadow(a, 2), OracleShadow(b, 4)
+        for k in range(7):
+            x = np.stack([orc.synth(300 + i, k, frames * 2).reshape(frames, 2) for i in range(n)])
+            with torch.cuda.stream(s):
+                dx = torch.from_numpy(x).to("cuda", non_blocking=False)
+                dy = torch.empty_like(dx)
+            s.synchronize()
+            a.mix_device(frames, dx.data_ptr(), dy.data_ptr(), stream=s.cuda_stream)   # asynchronous, on the caller's stream
+            yb = b.mix(x)                                                                 # the other batch meanwhile
+            s.synchronize()
+            ya = dy.cpu().numpy()
+            ok, nbad = same_bits(ya[2], sa.mix(x[2]))
+            assert ok, f"batch a buffer {k}: {nbad} samples differ"
+            ok, nbad = same_bits(yb[4], sb.mix(x[4]))
+            assert ok, f"batch b buffer {k}: {nbad} samples differ"
+        assert not sa.compare_state() and not sb.compare_state()
