@@ -30,6 +30,8 @@ struct KernelCtx {
     int frames;                         // frames in this chunk (<= OALSFX_MAX_CHUNK)
     long long io_stride;                // floats between consecutive instances in dst
     long long src_stride;               // floats between consecutive instances in src / wet_src
+    int* done;                          // [instance][slots]: written by the multichannel steady-state reverb kernel (1 = this chunk is
+                                        // done), read by the general kernel launched right after on the same list; nullptr otherwise
     unsigned long long* timeline;       // measurement only (OALSFX_DEBUG_TIMELINE): phase time stamps of sampled workgroups, else nullptr
 };
 

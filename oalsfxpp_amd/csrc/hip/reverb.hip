@@ -225,6 +225,10 @@ __device__ __forceinline__ void lds_barrier()
 // sources, the filtered input and the late feed of an earlier lane, are handed over through LDS rows), and vector
 // all-pass offsets of 16..63 samples (the all-pass outputs of the first lanes are evaluated ahead, up to three times,
 // and handed over).
+// CH == 8: the multichannel build (quad .. 7.1, channel count at run time): send and pan gains live in a second table,
+// the dry mix and the panning loop over the channels, and an instance that is not steady is not taken inside the kernel
+// (its LDS would have to be sized for the general path's 64 gain ramps) but flagged in ctx.done for the general kernel
+// that the host launches right after on the same list.
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
@@ -235,8 +239,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             ctx.timeline[((blockIdx.x >> 6) * NW + (threadIdx.x >> 6)) * 96 + ts_i++] = clock64();
     };
     stamp();
-    static_assert(CH <= 2, "the steady-state kernel is specialised for mono and stereo");
-    constexpr int kFloats = Lds<CH>::kFloats; // sized for the general path, which non-steady instances fall back to below
+    static_assert(CH <= 2 || CH == 8, "mono, stereo, or the multichannel build");
+    constexpr bool MC = CH > 2;
+    constexpr int kMcBase = ut::SIZE + 64 + 8 * kRow; // multichannel tables behind the modulation row and the hand-over rows:
+                                                      // GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
+    // mono / stereo: sized for the general path, which non-steady instances fall back to below
+    constexpr int kFloats = MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
+    const int nch = MC ? ctx.channels : CH;
     __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
     __shared__ float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     __shared__ int go_all[NW];
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // depend on each other, so the prologue costs one memory round trip after the list entry instead of three
     const int l4 = lane & 3;
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
-    const bool q_valid = lane < 8 * CH;
+    const bool q_valid = lane < 8 * CH && q_chan < nch;
     const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb; // per-lane (vector) reads of the parameter block
     const oalsfx_source_params& SG = ctx.source[inst];
     const unsigned v_seen = SS.seen_seq;
@@ -288,8 +297,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const float v_lpx0 = S.lp[l4].x[0], v_lpx1 = S.lp[l4].x[1], v_lpy0 = S.lp[l4].y[0], v_lpy1 = S.lp[l4].y[1];
     const float v_hpy0 = S.hp[l4].y[0], v_hpy1 = S.hp[l4].y[1];
     const float v_t60x = S.t60[l4][0][0], v_t60o1 = S.t60[l4][0][1], v_t60o2 = S.t60[l4][1][1];
-    const float v_gdir = SG.direct.gains[(lane >> 1) & 1][lane & 1];
-    const float v_gaux = SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
+    // send gains: mono / stereo lane = c * 2 + o (direct), c * 4 + k (aux); multichannel lane = c * 8 + o, c * 4 + k
+    const float v_gdir = MC ? SG.direct.gains[lane >> 3][lane & 7] : SG.direct.gains[(lane >> 1) & 1][lane & 1];
+    const float v_gaux = MC ? SG.aux[slot].gains[(lane >> 2) & 7][lane & 3] : SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
 
     // ---- is this instance in its steady state for the whole buffer? ----
     unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
@@ -331,11 +341,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     }
     stamp(); // [1] descriptors read, steady-state test done
 
-    unsigned aud_dir = 0, aud_aux = 0, aud_out = 0;
+    unsigned long long aud_dir = 0, aud_aux = 0, aud_out = 0; // which gains are audible (bit layout as the tables)
     int offset = 0;
     const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
-    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * CH * OALSFX_MAX_CHUNK : nullptr;
+    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * nch * OALSFX_MAX_CHUNK : nullptr;
     const float b2a = 0.288675134595F;
     if (go) {
         // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
@@ -357,20 +367,30 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             ch[coop::T60X] = v_t60x; ch[coop::T60O1] = v_t60o1; ch[coop::T60O2] = v_t60o2;
             ch[coop::LP_A1] = P.lp.a1; ch[coop::LP_A2] = P.lp.a2; ch[coop::HP_A1] = P.hp.a1; ch[coop::HP_A2] = P.hp.a2;
             ch[coop::T_L2] = v_tl2; ch[coop::T_H2] = v_th2; ch[coop::T_MID] = v_tmid;
-            utf[ut::GDIR + lane] = v_gdir;
+            if (!MC) utf[ut::GDIR + lane] = v_gdir;
         }
-        if (lane < 8) utf[ut::GAUX + lane] = v_gaux;
+        if (!MC && lane < 8) utf[ut::GAUX + lane] = v_gaux;
+        if (MC) {
+            utf[kMcBase + lane] = q_valid ? g_cur : 0.0F;
+            utf[kMcBase + 64 + lane] = v_gdir;
+            if (lane < 32) utf[kMcBase + 128 + lane] = v_gaux;
+        }
         if (lane == 0) {
             utu[ut::FEED4] = 4u * static_cast<unsigned>(P.late_feed_tap);
             utf[ut::MISC + 0] = P.density_gain; utf[ut::MISC + 1] = P.ap_feed_coeff; utf[ut::MISC + 2] = P.mix_x; utf[ut::MISC + 3] = P.mix_y;
             utf[ut::LPB + 0] = P.lp.b0; utf[ut::LPB + 1] = P.lp.b1; utf[ut::LPB + 2] = P.lp.b2; utf[ut::LPB + 3] = 0.0F;
             utf[ut::HPB + 0] = P.hp.b0; utf[ut::HPB + 1] = P.hp.b1; utf[ut::HPB + 2] = P.hp.b2; utf[ut::HPB + 3] = 0.0F;
         }
-        if (q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
-        aud_dir = static_cast<unsigned>(__ballot(lane < 4 && audible(v_gdir)));   // bit c * 2 + o
-        aud_aux = static_cast<unsigned>(__ballot(lane < 8 && audible(v_gaux)));   // bit c * 4 + k
+        if (!MC && q_valid) utf[ut::GOUT + (CH == 1 ? 2 * lane : lane)] = g_cur;
+        if (MC) {
+            aud_dir = __ballot((lane >> 3) < nch && (lane & 7) < nch && audible(v_gdir));  // bit c * 8 + o
+            aud_aux = __ballot(lane < 32 && (lane >> 2) < nch && audible(v_gaux));          // bit c * 4 + k
+        } else {
+            aud_dir = __ballot(lane < 4 && audible(v_gdir));   // bit c * 2 + o
+            aud_aux = __ballot(lane < 8 && audible(v_gaux));   // bit c * 4 + k
+        }
         if (CH == 1) { aud_dir &= 1u; aud_aux &= 0xFu; }
-        aud_out = static_cast<unsigned>(__ballot(q_valid && audible(g_cur)));
+        aud_out = __ballot(q_valid && audible(g_cur));        // multichannel: bit (stage * 4 + line) * 8 + channel
         if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
                                 ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
         offset = v_offset;
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // Software pipeline: inputs of tile k+1 are requested before tile k is computed (every tap is >= 2 tiles away).
     v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
     float n_in0 = 0.0F, n_in1 = 0.0F;
+    float n_inv[MC ? 8 : 1] = {}; // multichannel: the frame's input channels
     auto load4 = [&](unsigned t4x, int group, int r) -> v4f {
         const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
@@ -418,7 +439,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     int md_next = 0, md_cur = 0;
     auto issue_loads = [&](unsigned t4x, int posx) {
         const int px = min(posx, frames - 1);
-        if (CH == 2) {
+        if (MC) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < nch) n_inv[MC ? c : 0] = src[static_cast<size_t>(px) * nch + c];
+        } else if (CH == 2) {
             const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
             n_in0 = v.x; n_in1 = v.y;
         } else {
@@ -465,11 +490,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         const int pos = (tile << 6) + lane;
         const unsigned t4 = static_cast<unsigned>(offset + pos) << 2;
         float o0 = 0.0F, o1 = 0.0F;
+        float outv[MC ? 8 : 1] = {}; // multichannel: the output frame being accumulated
         v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
 
         // ---------------- P1: inputs, A-format, feed-forward half of the first shelf ----------------
         if (go) {
             const float in[2] = {n_in0, n_in1};
+            float inv[MC ? 8 : 1];
+#pragma unroll
+            for (int c = 0; c < (MC ? 8 : 1); ++c) inv[c] = n_inv[c];
             if (MD) {
                 md_cur = md_next;
                 if (mod_on && tile + 1 < tiles) md_next = next_mod_delays();
@@ -485,21 +514,40 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             }
             if (tile + 1 < tiles) issue_loads(t4 + 256u, pos + 64);
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
-            if (!first) {
+            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+            if (MC) {
+                // dry mix and B-format send, channel by channel (reference mix_source, src/oalsfxpp.cpp:2917-2982)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c >= nch) continue;
+                    if (first) {
+#pragma unroll
+                        for (int o = 0; o < 8; ++o)
+                            if (aud_dir & (1ULL << (c * 8 + o))) outv[MC ? o : 0] += inv[MC ? c : 0] * utf[kMcBase + 64 + c * 8 + o];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (aud_aux & (1ULL << (c * 4 + k))) wet[k] += inv[MC ? c : 0] * utf[kMcBase + 128 + c * 4 + k];
+                }
+                if (!first) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nch) outv[MC ? c : 0] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
+                }
+            } else if (!first) {
                 o0 = mixbuf[pos];
                 if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
             } else {
                 const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
                 const float g[4] = {gd.x, gd.y, gd.z, gd.w};
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
+                for (int c = 0; c < (MC ? 0 : CH); ++c) {
                     if (aud_dir & (1u << (c * 2 + 0))) o0 += in[c] * g[c * 2 + 0];
                     if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) o1 += in[c] * g[c * 2 + 1];
                 }
             }
-            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
+            for (int c = 0; c < (MC ? 0 : CH); ++c) {
                 const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
                 const float g[4] = {ga.x, ga.y, ga.z, ga.w};
 #pragma unroll
@@ -729,15 +777,35 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             scatter2(r01, r23, sx, sy);
             store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
             const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
+            if (MC) {
+                // early lines 0..3 then late lines 0..3, each into every audible channel (reference src/oalsfxpp.cpp:6142-6166)
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) {
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (aud_out & (1ULL << (k * 8 + c))) outv[MC ? c : 0] += data[k] * utf[kMcBase + k * 8 + c];
+                }
+                if (last) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nch) dst[static_cast<size_t>(pos) * nch + c] = outv[MC ? c : 0];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nch) mixbuf[c * OALSFX_MAX_CHUNK + pos] = outv[MC ? c : 0];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (MC ? 0 : 8); k += 2) {
                 const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k);
                 if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
                 if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
                 if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
                 if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
             }
-            if (last) {
+            if (MC) {
+                // stored above
+            } else if (last) {
                 if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
                 else dst[pos] = o0;
             } else {
@@ -767,12 +835,17 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             S.offset = offset + frames;
             if (MD && mod_on) S.mod_filter = mod_f;
         }
-        if (first && lane < CH) send_history_follow(ctx, inst, lane, CH, frames, src);
+        if (first && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
     }
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
-    if (valid && !go) {
-        KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
-        reverb_general_call<CH>(&copy, slot, inst, flags & 0xFF, lds, lane);
+    if constexpr (MC) {
+        // the general kernel follows on the same list: tell it which instances are done
+        if (valid && lane == 0) ctx.done[sidx] = go ? 1 : 0;
+    } else {
+        if (valid && !go) {
+            KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
+            reverb_general_call<CH>(&copy, slot, inst, flags & 0xFF, lds, lane);
+        }
     }
     stamp(); // state handed back
 }
@@ -1361,7 +1434,10 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wave_in_block;
     if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
-    reverb_general_instance<CH>(ctx, slot, __builtin_amdgcn_readfirstlane(list[w]), flags, lds_all[wave_in_block], lane);
+    const int inst = __builtin_amdgcn_readfirstlane(list[w]);
+    // launched behind the multichannel steady-state kernel on the same list: skip what that kernel has done
+    if (ctx.done && __builtin_amdgcn_readfirstlane(ctx.done[static_cast<size_t>(inst) * ctx.slots + slot]) != 0) return;
+    reverb_general_instance<CH>(ctx, slot, inst, flags, lds_all[wave_in_block], lane);
 }
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
@@ -1372,6 +1448,11 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
+    if (c.channels > 2) {
+        // multichannel: the most general build only; the caller launches the general kernel on the same list right after
+        OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        return;
+    }
     if (c.channels == 1) {
         if (short_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
         else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);

@@ -460,3 +460,15 @@ def test_two_batches_and_a_caller_stream():
             ok, nbad = same_bits(yb[4], sb.mix(x[4]))
             assert ok, f"batch b buffer {k}: {nbad} samples differ"
         assert not sa.compare_state() and not sb.compare_state()
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_5POINT1_REAR, desc.FMT_6POINT1, desc.FMT_7POINT1])
+def test_multichannel_reverb_on_the_steady_kernel(fmt):
+    """Quad .. 7.1 outputs run the multichannel build of the steady-state reverb kernel (channel count at run time, general
+    kernel right behind it for what it does not take): default, close-tap, modulated and short-tap presets, as the only
+    slot, behind another slot (accumulating onto mixbuf) and in front of one (writing mixbuf)."""
+    picks = [0, 2, 23, 3, 25, 95]
+    script = [("mix", 256)] * 7 + [("mix", 2048), ("mix", 64), ("mix", 100), ("mix", 256)]
+    run_batch(fmt, 48000, 1, [[(0, preset_effect(i, desc.EAX_REVERB if k % 2 == 0 else desc.REVERB))] for k, i in enumerate(picks)], script)
+    two = [[(0, E(desc.CHORUS)), (1, preset_effect(23))], [(0, preset_effect(3)), (1, E(desc.ECHO))], [(0, E(desc.EAX_REVERB)), (1, E(desc.REVERB))]]
+    run_batch(fmt, 44100, 2, two, script[:9])
