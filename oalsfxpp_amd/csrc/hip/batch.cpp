@@ -78,7 +78,7 @@ struct oalsfx_batch {
     size_t filtered_capacity = 0;                 // floats per send plane
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
-    int* d_done = nullptr;                        // [n*slots] multichannel reverbs: hand-off from the steady-state to the general kernel
+    int* d_progress = nullptr;                    // [n*slots] hand-off from the steady-state reverb kernel to the general kernel behind it
     // Per slot the list is: ring-light types in ascending order (list_offset / list_count per type), then the reverb instances
     // believed steady (reverb, EAX reverb: list_offset / steady_count), then every other reverb instance of both types
     // (general_offset / general_count).  list_count of a reverb type counts all its instances.
@@ -421,7 +421,7 @@ constexpr int kTimedGeneralOffset = 16; // TimedLaunch::type of a reverb type's 
 constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
 
 // Can the steady-state kernel be used for this chunk at all?
-bool steady_kernel_usable(const KernelCtx& ctx) { return (ctx.frames & 63) == 0 && !(debug_flags() & 8); }
+bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 64 && !(debug_flags() & 8); }
 
 // One steady-state launch for the believed-steady instances of both reverb types (adjacent in the list; the kernel reads
 // the type per instance).
@@ -430,15 +430,20 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     const int r = OALSFX_REVERB, e = OALSFX_EAX_REVERB;
     const int* list = b->d_lists + b->list_offset[slot][r];
     const int count = b->steady_count[slot][r] + b->steady_count[slot][e];
+    // Mono / stereo chunks of whole tiles: one launch, an instance that turns out not to be steady falls back inside it.
+    // More than two channels, or a ragged chunk: the steady-state kernel takes the whole tiles of the instances that are
+    // steady and notes per instance how far it got; the general kernel right behind it finishes every instance.
+    const bool hand_over = ctx.channels > 2 || (ctx.frames & 63) != 0;
     KernelCtx c = ctx;
-    c.done = ctx.channels > 2 ? b->d_done : nullptr;
+    c.frames = ctx.frames & ~63;
+    c.progress = hand_over ? b->d_progress : nullptr;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
         oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->close_taps[slot][r] || b->close_taps[slot][e],
                                          b->modulated[slot][r] || b->modulated[slot][e], b->short_taps[slot][r] || b->short_taps[slot][e], stream);
     }
-    if (ctx.channels > 2) {
-        // more than two channels: that kernel has no fallback inside; the general kernel takes what it flagged as not done
+    if (hand_over) {
+        c.frames = ctx.frames;
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
         oalsfx_hip::launch_reverb_general(c, slot, list, count, flags, stream);
     }
@@ -644,10 +649,8 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
-    if (channels > 2) {
-        ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_done), total * sizeof(int)), "hipMalloc(done flags)");
-        ok = ok && b->hip_ok(hipMemsetAsync(b->d_done, 0, total * sizeof(int), b->stream), "hipMemsetAsync(done flags)");
-    }
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
     if (ok && std::getenv("OALSFX_DEBUG_TIMELINE")) {
@@ -680,7 +683,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (hipEvent_t e : b->event_pool) hipEventDestroy(e);
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
-    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_done); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     for (int k = 0; k < kSideStreams; ++k) {
         if (b->side_stream[k]) hipStreamDestroy(b->side_stream[k]);
         if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);

@@ -227,8 +227,9 @@ __device__ __forceinline__ void lds_barrier()
 // and handed over).
 // CH == 8: the multichannel build (quad .. 7.1, channel count at run time): send and pan gains live in a second table,
 // the dry mix and the panning loop over the channels, and an instance that is not steady is not taken inside the kernel
-// (its LDS would have to be sized for the general path's 64 gain ramps) but flagged in ctx.done for the general kernel
-// that the host launches right after on the same list.
+// (its LDS would have to be sized for the general path's 64 gain ramps) but left, through ctx.progress, to the general
+// kernel that the host launches right after on the same list.  The mono / stereo builds work the same way when the host
+// hands them the whole tiles of a ragged chunk (ctx.progress set): the general kernel then finishes every instance.
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
@@ -838,10 +839,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         if (first && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
     }
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
-    if constexpr (MC) {
-        // the general kernel follows on the same list: tell it which instances are done
-        if (valid && lane == 0) ctx.done[sidx] = go ? 1 : 0;
-    } else {
+    if (MC || ctx.progress != nullptr) {
+        // the general kernel follows on the same list: tell it how far this instance got
+        if (valid && lane == 0) ctx.progress[sidx] = go ? frames : 0;
+    } else if constexpr (!MC) {
         if (valid && !go) {
             KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
             reverb_general_call<CH>(&copy, slot, inst, flags & 0xFF, lds, lane);
@@ -873,6 +874,9 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
+    // frames of this chunk the steady-state kernel has done already (launched right before on the same list), else 0
+    const int resume = ctx.progress ? __builtin_amdgcn_readfirstlane(ctx.progress[sidx]) : 0;
+    if (resume >= frames) return;
     // parameters are read-only for the whole launch: address space 4 (constant) makes every access a scalar load
     typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
     typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
@@ -985,11 +989,14 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
     const float apc = P.ap_feed_coeff, mx = P.mix_x, my = P.mix_y;
 
     gstamp(); // prologue done
-    for (int base = 0; base < frames;) {
-        int todo = min(frames - base, OALSFX_RV_MAX_UPDATE);
+    for (int base = resume; base < frames;) {
+        // the reference's blocks start every 256 frames of the call; carrying on behind the steady-state kernel may start in
+        // the middle of one (at a multiple of 64), and the ramp counter still refers to the block's own start
+        const int block_start = (base == resume) ? base - (base % OALSFX_RV_MAX_UPDATE) : base;
+        int todo = min(frames - base, OALSFX_RV_MAX_UPDATE - (base - block_start));
         if (OALSFX_RV_FADE_SAMPLES - fade_count > 0) todo = min(todo, OALSFX_RV_FADE_SAMPLES - fade_count);
         const bool faded = fade_count < OALSFX_RV_FADE_SAMPLES; // fade < 1.0
-        const int counter = frames - base;
+        const int counter = frames - block_start;
 
         // output gain ramps of this chunk (MixHelpers::mix, reference src/oalsfxpp.cpp:2762-2786)
         const float delta = 1.0F / static_cast<float>(counter);
@@ -1435,8 +1442,6 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
     const int w = blockIdx.x * 4 + wave_in_block;
     if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
-    // launched behind the multichannel steady-state kernel on the same list: skip what that kernel has done
-    if (ctx.done && __builtin_amdgcn_readfirstlane(ctx.done[static_cast<size_t>(inst) * ctx.slots + slot]) != 0) return;
     reverb_general_instance<CH>(ctx, slot, inst, flags, lds_all[wave_in_block], lane);
 }
 

@@ -472,3 +472,15 @@ def test_multichannel_reverb_on_the_steady_kernel(fmt):
     run_batch(fmt, 48000, 1, [[(0, preset_effect(i, desc.EAX_REVERB if k % 2 == 0 else desc.REVERB))] for k, i in enumerate(picks)], script)
     two = [[(0, E(desc.CHORUS)), (1, preset_effect(23))], [(0, preset_effect(3)), (1, E(desc.ECHO))], [(0, E(desc.EAX_REVERB)), (1, E(desc.REVERB))]]
     run_batch(fmt, 44100, 2, two, script[:9])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO, desc.FMT_5POINT1])
+def test_ragged_calls_hand_over_to_the_general_kernel(fmt):
+    """Call sizes that are not whole 64-frame tiles (480 = 10 ms at 48 kHz, 441, 65, 127, 2048 + 100): the steady-state kernel
+    takes the whole tiles of the settled instances, the general kernel carries each instance on from there -- in the middle
+    of one of the reference's 256-frame blocks -- and does the unsettled ones from the start."""
+    picks = [0, 2, 23, 3, 25, 95, 0, 112]
+    setups = [[(0, preset_effect(i, desc.EAX_REVERB if k % 3 else desc.REVERB))] for k, i in enumerate(picks)]
+    script = [("mix", 256)] * 3 + [("mix", 480), ("mix", 480), ("mix", 441), ("mix", 65), ("mix", 127), ("mix", 2048 + 100), ("mix", 64), ("mix", 63)]
+    script += [("set", 0, 0, preset_effect(5)), ("set", 6, 0, preset_effect(60)), ("apply",), ("mix", 480), ("mix", 480), ("mix", 300), ("mix", 256)]
+    run_batch(fmt, 48000, 1, setups, script)
