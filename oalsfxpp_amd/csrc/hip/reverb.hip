@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     // ---- is this instance in its steady state for the whole buffer? ----
     unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
     unsigned short_mask = 0; // ST build: tap groups with a source inside the tile
-    bool go = valid && (frames & 63) == 0 && !(flags & kFiltered) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
+    bool go = valid && (frames & 63) == 0 && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
               (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
     const bool mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
     const float g_cur = v_gcur;
@@ -402,6 +402,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
     float n_in0 = 0.0F, n_in1 = 0.0F;
     float n_inv[MC ? 8 : 1] = {}; // multichannel: the frame's input channels
+    // after the send-filter pre-pass the auxiliary send has its own input plane (the direct send's is `src`)
+    const bool filtered = (flags & kFiltered) != 0;
+    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    float n_w0 = 0.0F, n_w1 = 0.0F;
+    float n_wv[MC ? 8 : 1] = {};
     auto load4 = [&](unsigned t4x, int group, int r) -> v4f {
         const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
@@ -444,11 +449,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if (c < nch) n_inv[MC ? c : 0] = src[static_cast<size_t>(px) * nch + c];
+            if (filtered) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < nch) n_wv[MC ? c : 0] = wsrc[static_cast<size_t>(px) * nch + c];
+            }
         } else if (CH == 2) {
             const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
             n_in0 = v.x; n_in1 = v.y;
+            if (filtered) {
+                const float2 u = *reinterpret_cast<const float2*>(wsrc + static_cast<size_t>(px) * 2);
+                n_w0 = u.x; n_w1 = u.y;
+            }
         } else {
             n_in0 = src[px];
+            if (filtered) n_w0 = wsrc[px];
         }
         if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN);
         if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
@@ -497,9 +512,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         // ---------------- P1: inputs, A-format, feed-forward half of the first shelf ----------------
         if (go) {
             const float in[2] = {n_in0, n_in1};
-            float inv[MC ? 8 : 1];
+            const float win[2] = {filtered ? n_w0 : n_in0, filtered ? n_w1 : n_in1}; // what the auxiliary send sees
+            float inv[MC ? 8 : 1], winv[MC ? 8 : 1];
 #pragma unroll
-            for (int c = 0; c < (MC ? 8 : 1); ++c) inv[c] = n_inv[c];
+            for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
             if (MD) {
                 md_cur = md_next;
                 if (mod_on && tile + 1 < tiles) md_next = next_mod_delays();
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (aud_aux & (1ULL << (c * 4 + k))) wet[k] += inv[MC ? c : 0] * utf[kMcBase + 128 + c * 4 + k];
+                        if (aud_aux & (1ULL << (c * 4 + k))) wet[k] += winv[MC ? c : 0] * utf[kMcBase + 128 + c * 4 + k];
                 }
                 if (!first) {
 #pragma unroll
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
                 const float g[4] = {ga.x, ga.y, ga.z, ga.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (aud_aux & (1u << (c * 4 + k))) wet[k] += in[c] * g[k];
+                    if (aud_aux & (1u << (c * 4 + k))) wet[k] += win[c] * g[k];
             }
             v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
             a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
@@ -836,7 +852,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
             S.offset = offset + frames;
             if (MD && mod_on) S.mod_filter = mod_f;
         }
-        if (first && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
+        if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
     }
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
     if (MC || ctx.progress != nullptr) {

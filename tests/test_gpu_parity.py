@@ -484,3 +484,16 @@ def test_ragged_calls_hand_over_to_the_general_kernel(fmt):
     script = [("mix", 256)] * 3 + [("mix", 480), ("mix", 480), ("mix", 441), ("mix", 65), ("mix", 127), ("mix", 2048 + 100), ("mix", 64), ("mix", 63)]
     script += [("set", 0, 0, preset_effect(5)), ("set", 6, 0, preset_effect(60)), ("apply",), ("mix", 480), ("mix", 480), ("mix", 300), ("mix", 256)]
     run_batch(fmt, 48000, 1, setups, script)
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_STEREO, desc.FMT_5POINT1])
+def test_send_filters_with_settled_reverbs(fmt):
+    """Send filters do not take the reverbs off the steady-state kernel: it reads the direct and the auxiliary send's filtered
+    planes instead of the raw input.  Presets of every build, filters on different sends, many whole-tile buffers."""
+    picks = [0, 2, 23, 3, 25]
+    setups = [[(0, preset_effect(i)), (1, E(desc.ECHO))] for i in picks]
+    script = [("mix", 256)] * 3
+    script += [("send", 0, -1, 0.8, 0.4, 1.0), ("send", 1, 0, 1.0, 0.3, 0.5), ("send", 2, 0, 0.6, 1.0, 0.2), ("send", 3, 1, 1.0, 0.5, 1.0),
+               ("send", 4, -1, 1.0, 0.7, 0.7), ("send", 4, 0, 0.9, 0.2, 0.9), ("apply",)]
+    script += [("mix", 256)] * 6 + [("mix", 480), ("mix", 2048), ("mix", 256)]
+    run_batch(fmt, 48000, 2, setups, script)
