@@ -511,6 +511,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     for (int done = 0; done < frames;) {
         const int n = std::min(frames - done, OALSFX_MAX_CHUNK);
         const float* chunk_src = src + static_cast<size_t>(done) * b->channels;
+        ctx.raw_src = chunk_src;
         ctx.dst = dst + static_cast<size_t>(done) * b->channels;
         ctx.frames = n;
         if (filtered) {

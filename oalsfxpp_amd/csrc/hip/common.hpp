@@ -20,8 +20,10 @@ struct KernelCtx {
     float* const* rings;                // [instance][slots] -> ring slab of that slot (or nullptr)
     const oalsfx_source_params* source; // [instance]
     oalsfx_source_state* source_state;  // [instance]: histories of the send filters
-    const float* src;                   // [instance][frames][channels] interleaved input of this chunk as the direct send sees it
-    const float* wet_src;               // ... as this slot's auxiliary send sees it (== src unless kFiltered)
+    const float* raw_src;               // [instance][frames][channels] interleaved input of this chunk (stride io_stride)
+    const float* src;                   // ... as the direct send sees it: raw_src, or with kFiltered the pre-pass plane of the direct send
+                                        // (stride src_stride), valid for the instances that have a send filter switched on
+    const float* wet_src;               // ... as this slot's auxiliary send sees it (same rule)
     long long wet_plane;                // floats between the wet_src planes of consecutive slots (0 unless kFiltered)
     float* dst;                         // [instance][frames][channels] interleaved output of this chunk
     float* mixbuf;                      // [instance][channels][OALSFX_MAX_CHUNK] planar accumulator (multi-slot only)
@@ -41,8 +43,8 @@ struct KernelCtx {
 enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
-    kFiltered = 16, // the send filters ran as a pre-pass (k_send_filters): src / wet_src are its outputs and the filter
-                    // histories are already up to date
+    kFiltered = 16, // the send-filter pre-pass (k_send_filters) ran: for the instances with a filter switched on, the planes at
+                    // filtered_src / wet planes hold their sends' inputs and their filter histories are up to date
 };
 
 constexpr int kWave = 64;
@@ -134,6 +136,18 @@ __device__ __forceinline__ float biquad_step(const oalsfx_biquad_t& c, oalsfx_hi
     h.y[1] = h.y[0];
     h.y[0] = y;
     return y;
+}
+
+// Does any enabled send of this instance have a shelf filter switched on?  The send-filter pre-pass handles exactly those
+// instances (all their sends); the effect kernels read the pre-pass planes for them and the raw input for the others.
+__device__ __forceinline__ bool instance_has_send_filter(const KernelCtx& ctx, int inst)
+{
+    typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
+    ConstSourceParams& P = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
+    int any = P.direct.filter_type;
+    for (int s = 0; s < ctx.slots; ++s)
+        if (P.aux[s].out_channels != 0) any |= P.aux[s].filter_type;
+    return any != OALSFX_AF_NONE;
 }
 
 // Pass-through sends (ActiveFilters::none): the histories of both shelf filters of every enabled send follow the input

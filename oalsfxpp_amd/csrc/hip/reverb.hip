@@ -344,7 +344,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 
     unsigned long long aud_dir = 0, aud_aux = 0, aud_out = 0; // which gains are audible (bit layout as the tables)
     int offset = 0;
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+    // after the send-filter pre-pass an instance with a filter reads its sends' planes, any other instance the raw input
+    const bool filtered = (flags & kFiltered) != 0 && instance_has_send_filter(ctx, inst);
+    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+    const float* wsrc = src;
+    if (filtered) {
+        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    }
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * nch * OALSFX_MAX_CHUNK : nullptr;
     const float b2a = 0.288675134595F;
@@ -402,9 +409,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
     float n_in0 = 0.0F, n_in1 = 0.0F;
     float n_inv[MC ? 8 : 1] = {}; // multichannel: the frame's input channels
-    // after the send-filter pre-pass the auxiliary send has its own input plane (the direct send's is `src`)
-    const bool filtered = (flags & kFiltered) != 0;
-    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
     float n_w0 = 0.0F, n_w1 = 0.0F;
     float n_wv[MC ? 8 : 1] = {};
     auto load4 = [&](unsigned t4x, int group, int r) -> v4f {
@@ -995,9 +999,13 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         g_tgt = q_stage ? P.late_pan[q_line][q_chan] : P.early_pan[q_line][q_chan];
     }
 
-    const bool filtered = (flags & kFiltered) != 0;
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
-    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    const bool filtered = (flags & kFiltered) != 0 && instance_has_send_filter(ctx, inst);
+    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+    const float* wsrc = src;
+    if (filtered) {
+        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    }
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
 

@@ -5,19 +5,25 @@
 namespace oalsfx_hip {
 
 // Send shelf filters as a pre-pass (reference apply_filters, src/oalsfxpp.cpp:3101-3143, called from mix_source :2929-2965).
-// One wavefront per instance; lane = send * 8 + input channel runs that send's two biquads over the chunk in sample order,
-// so the recurrences round like the reference's.  Sends without a filter copy their input, which lets the effect kernels
-// read every send from the same place.  Runs only while some instance of the batch has a filter switched on.
+// One lane per (instance, send, input channel): it runs that send's two biquads over the chunk in sample order, so the
+// recurrences round like the reference's; a wavefront packs as many instances as fit its 64 lanes (16 for a stereo batch
+// with one slot).  Only instances with a filter switched on are handled (their sends without one copy their input, which
+// lets the effect kernels read every send of such an instance from the same place).  Runs only while some instance of the
+// batch has a filter switched on.
 __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float* __restrict__ src_all, long long src_stride,
                                                       float* __restrict__ filtered, size_t send_floats, int instances)
 {
     const int lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (inst >= instances) return;
     const int channels = ctx.channels;
-    const int send = lane >> 3;
-    const int c = lane & 7;
-    if (send > ctx.slots || c >= channels) return;
+    const int lanes_per_instance = (1 + ctx.slots) * channels;   // <= 5 * 8
+    const int instances_per_wave = 64 / lanes_per_instance;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int sub = lane / lanes_per_instance, r = lane % lanes_per_instance;
+    const int inst = wave * instances_per_wave + sub;
+    if (sub >= instances_per_wave || inst >= instances) return;
+    if (!instance_has_send_filter(ctx, inst)) return; // the effect kernels read the raw input for this instance and keep its histories
+    const int send = r / channels;
+    const int c = r % channels;
     const oalsfx_source_params& P = ctx.source[inst];
     const oalsfx_send_params& sp = send == 0 ? P.direct : P.aux[send - 1];
     if (send > 0 && sp.out_channels == 0) return; // null slot: the send is disabled and its history frozen
@@ -29,10 +35,17 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
     const float* src = src_all + static_cast<size_t>(inst) * src_stride + c;
     float* out = filtered + static_cast<size_t>(send) * send_floats + static_cast<size_t>(inst) * ctx.src_stride + c;
     const int frames = ctx.frames;
+    // eight frames at a time, the next eight requested before the current eight are filtered: the recurrence never waits for
+    // the strided input
+    float nx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nx[k] = (k < frames) ? src[static_cast<size_t>(k) * channels] : 0.0F;
     for (int base = 0; base < frames; base += 8) {
         float x[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (base + k < frames) ? src[static_cast<size_t>(base + k) * channels] : 0.0F;
+        for (int k = 0; k < 8; ++k) x[k] = nx[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nx[k] = (base + 8 + k < frames) ? src[static_cast<size_t>(base + 8 + k) * channels] : 0.0F;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (base + k >= frames) break;
@@ -54,7 +67,9 @@ void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_s
                          hipStream_t stream)
 {
     if (instances <= 0 || ctx.frames <= 0) return;
-    hipLaunchKernelGGL(k_send_filters, dim3((instances + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, instances);
+    const int instances_per_wave = 64 / ((1 + ctx.slots) * ctx.channels);
+    const int waves = (instances + instances_per_wave - 1) / instances_per_wave;
+    hipLaunchKernelGGL(k_send_filters, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, instances);
 }
 
 // ---- synthetic benchmark input, generated in device memory ----

@@ -545,9 +545,13 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
     const bool first = (flags & kFirst) != 0;
     const bool last = (flags & kLast) != 0;
-    const bool filtered = (flags & kFiltered) != 0;
-    const float* src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
-    const float* wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    const bool filtered = (flags & kFiltered) != 0 && instance_has_send_filter(ctx, inst);
+    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+    const float* wsrc = src;
+    if (filtered) {
+        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    }
     float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
     float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
     const bool send_on = SRC.aux[slot].out_channels != 0;
