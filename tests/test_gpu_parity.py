@@ -499,3 +499,42 @@ def test_send_filters_with_settled_reverbs(fmt):
                ("send", 4, -1, 1.0, 0.7, 0.7), ("send", 4, 0, 0.9, 0.2, 0.9), ("apply",)]
     script += [("mix", 256)] * 6 + [("mix", 480), ("mix", 2048), ("mix", 256)]
     run_batch(fmt, 48000, 2, setups, script)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OALSFX_FUZZ_BATCHES", "8"))))
+def test_random_batches(seed):
+    """Larger random batches (several workgroups, reverb types, presets and random properties mixed inside a workgroup),
+    mostly whole-tile calls so that the steady-state builds do the work, with changes, filters and ragged calls in between."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect
+    rng = random.Random(99 + seed)
+    fmt = rng.choice([desc.FMT_MONO, desc.FMT_STEREO, desc.FMT_STEREO, desc.FMT_5POINT1])
+    rate = rng.choice([44100, 48000, 48000])
+    slots = rng.randint(1, 2)
+    n = rng.choice([13, 29, 41])
+
+    def pick():
+        r = rng.random()
+        if r < 0.45:
+            return preset_effect(rng.randrange(113), rng.choice([desc.REVERB, desc.EAX_REVERB]))
+        if r < 0.7:
+            return random_effect(rng, rng.choice([desc.REVERB, desc.EAX_REVERB]))
+        return random_effect(rng, rng.randrange(12))
+
+    setups = [[(s, pick()) for s in range(slots)] for _ in range(n)]
+    script = [("mix", 256)] * 2
+    for _ in range(9):
+        r = rng.random()
+        if r < 0.6:
+            script.append(("mix", rng.choice([64, 128, 256, 256, 256, 512, 2048 + 64])))
+        elif r < 0.75:
+            script.append(("mix", rng.choice([1, 100, 480, 441])))
+        elif r < 0.9:
+            script.append(("set", rng.randrange(n), rng.randrange(slots), pick()))
+            script.append(("apply",))
+        else:
+            script.append(("send", rng.randrange(n), rng.randint(-1, slots - 1), rng.uniform(0.2, 1.0), rng.choice([1.0, rng.uniform(0.1, 1.0)]), 1.0))
+            script.append(("apply",))
+    script += [("mix", 256)]
+    check = sorted(rng.sample(range(n), 8))
+    run_batch(fmt, rate, slots, setups, script, check_instances=check)
