@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 FRAMES = 256
 CHANNELS = 2
 BYTES_PER_FRAME = 208          # 16 B I/O + 24 fp32 delay-line reads + 24 fp32 delay-line writes
-TIMED_EVERY = int(os.environ.get("OALSFX_TIMED_EVERY", "4"))
+TIMED_EVERY = int(os.environ.get("OALSFX_TIMED_EVERY", "8"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 METRIC = "Msamples/sec EAX reverb, 256-frame buffers, batch=4096; % HBM roofline"
 METRICS = {
@@ -181,7 +181,7 @@ def main():
     sharding.barrier()
     torch.cuda.synchronize()
 
-    # every 4th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
+    # every 8th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
     # be part of `value`
     batch.kernel_timing(0 if args.no_kernel_timing else TIMED_EVERY)
     t0 = time.perf_counter()
