@@ -182,7 +182,8 @@ void release_slab(oalsfx_batch* b, size_t idx)
     }
 }
 
-constexpr int kSettleFrames = 2 * OALSFX_RV_FADE_SAMPLES; // a cross-fade (128 frames) and the gain ramp of one call are over
+constexpr int kSettleFrames = OALSFX_RV_FADE_SAMPLES; // the cross-fade (128 frames) is over, and with it at least one call, whose end
+                                                      // snaps the output gains to their targets (reference MixHelpers::mix)
 
 // Host-side belief about which reverb instances the steady-state kernel will fully process: they are listed first and go
 // to that kernel, the others straight to the general kernel (a speed hint; the steady-state kernel decides on the device
