@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -58,15 +59,22 @@ struct oalsfx_batch {
     std::vector<float*> h_rings;                  // [n*slots]
     std::vector<size_t> ring_floats;              // [n*slots] size class of the slab held
     std::vector<uint8_t> inst_dirty;              // [n]
+    // Host-side belief about the reverb slots, kept incrementally (a parameter change touches its own slot only):
     std::vector<int> since_update;                // [n*slots] frames mixed since the slot's last parameter update (capped)
-    int unsettled[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // reverb instances per list not yet believed steady
-    bool close_taps[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // some reverb of the list has a tap between one and two tiles
-    bool short_taps[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {}; // some reverb of the list has a tap shorter than one tile
-    bool modulated[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};  // some reverb of the list has, or had, a modulated late line (sticky:
-                                                               // the depth smoother keeps moving long after the depth is set to 0)
+    std::vector<uint8_t> slot_class;              // [n*slots] kClass* bits of the slot's current parameters
+    std::vector<size_t> settling;                 // reverb slots updated less than kSettleFrames ago
+    std::vector<uint8_t> in_settling;             // [n*slots] membership flag of `settling`
+    int n_close[OALSFX_MAX_SLOTS] = {};           // per slot: reverbs with a tap between one and two tiles ...
+    int n_short[OALSFX_MAX_SLOTS] = {};           // ... with a tap shorter than one tile
+    bool modulated[OALSFX_MAX_SLOTS] = {};        // some reverb of the slot has, or had, a modulated late line (sticky: the depth
+                                                  // smoother keeps moving long after the depth is set to 0)
+    int n_filtered = 0;                           // instances with a send filter switched on
     std::vector<int> dirty_list;
     bool lists_dirty = true;
-    bool filters_active = false;
+    // Instances a setter has written since they were last applied: apply_changes() visits only these (for the others the
+    // reference's comparison of deferred and active properties finds nothing by construction).
+    std::vector<uint8_t> touched;                 // [n]
+    std::vector<int> touched_list;
 
     // device
     oalsfx_slot_params* d_params = nullptr;
@@ -96,6 +104,15 @@ struct oalsfx_batch {
     size_t io_capacity = 0;
 
     unsigned long long* d_timeline = nullptr;    // measurement only (OALSFX_DEBUG_TIMELINE=<file>)
+    // Parameter uploads: the changed records are packed into pinned memory, copied in one piece and scattered on the device;
+    // two buffers take turns so that the host never waits for the stream.
+    struct Stage { char* host = nullptr; char* dev = nullptr; size_t capacity = 0; hipEvent_t done = nullptr; bool pending = false; };
+    Stage stage[2];
+    int stage_turn = 0;
+    hipEvent_t ev_uploaded = nullptr;             // parameter uploads of the batch's own stream -> a caller's launch stream
+    hipEvent_t ev_mixed = nullptr;                // last launch on a caller's stream -> parameter uploads that overwrite what it reads
+    hipStream_t last_launch_stream = nullptr;
+
     hipStream_t stream = nullptr;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
     // is populated they run side by side on these streams, forked from and joined to the launch stream with events
@@ -141,36 +158,21 @@ bool range_ok(oalsfx_batch* b, int first, int count)
     return true;
 }
 
+void mark_touched(oalsfx_batch* b, int first, int count)
+{
+    for (int i = first; i < first + count; ++i)
+        if (!b->touched[i]) {
+            b->touched[i] = 1;
+            b->touched_list.push_back(i);
+        }
+}
+
 void mark_dirty(oalsfx_batch* b, int i)
 {
     if (!b->inst_dirty[i]) {
         b->inst_dirty[i] = 1;
         b->dirty_list.push_back(i);
     }
-}
-
-// copies [lo, hi) elements of a host shadow array to the device
-template <typename T>
-bool upload_range(oalsfx_batch* b, T* dev, const T* host, size_t lo, size_t hi)
-{
-    if (hi <= lo) return true;
-    return b->hip_ok(hipMemcpyAsync(dev + lo, host + lo, (hi - lo) * sizeof(T), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(H2D)");
-}
-
-// uploads the elements flagged in `flags` as maximal contiguous runs
-template <typename T>
-bool upload_flagged(oalsfx_batch* b, T* dev, const T* host, const std::vector<uint8_t>& flags)
-{
-    size_t i = 0;
-    const size_t n = flags.size();
-    while (i < n) {
-        if (!flags[i]) { ++i; continue; }
-        size_t j = i;
-        while (j < n && flags[j]) ++j;
-        if (!upload_range(b, dev, host, i, j)) return false;
-        i = j;
-    }
-    return true;
 }
 
 void release_slab(oalsfx_batch* b, size_t idx)
@@ -185,69 +187,112 @@ void release_slab(oalsfx_batch* b, size_t idx)
 constexpr int kSettleFrames = OALSFX_RV_FADE_SAMPLES; // the cross-fade (128 frames) is over, and with it at least one call, whose end
                                                       // snaps the output gains to their targets (reference MixHelpers::mix)
 
-// Host-side belief about which reverb instances the steady-state kernel will fully process: they are listed first and go
-// to that kernel, the others straight to the general kernel (a speed hint; the steady-state kernel decides on the device
-// from the real state and falls back by itself).
-bool reverb_settled(const oalsfx_batch* b, size_t idx)
+// What the host remembers of a slot's parameters (a speed hint only: the kernels decide from the device state).
+enum : uint8_t {
+    kClassReverb = 1,  // reverb or EAX reverb
+    kClassSteady = 2,  // parameters the steady-state kernel builds accept
+    kClassClose = 4,   // shortest tap distance 64..127 samples
+    kClassShort = 8,   // shortest tap distance below 64 samples
+    kClassModulated = 16,
+};
+
+uint8_t classify_slot(const oalsfx_slot_params& sp)
 {
-    const oalsfx_reverb_params& p = b->h_params[idx].u.reverb;
-    if (b->since_update[idx] < kSettleFrames) return false;
+    if (sp.type != OALSFX_REVERB && sp.type != OALSFX_EAX_REVERB) return 0;
+    const oalsfx_reverb_params& p = sp.u.reverb;
+    uint8_t cls = kClassReverb | kClassSteady;
     const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
+    int lo = 1 << 30;
     for (int j = 0; j < 4; ++j) {
         // what the most general build of the steady-state kernel accepts: early / late taps of any length, all-pass
         // offsets from a quarter tile, line offsets from one tile
         if (p.early_tap[j] < 0 || p.early_ap_off[j] < 16 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 16 ||
             p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap)
-            return false;
+            cls &= static_cast<uint8_t>(~kClassSteady);
+        lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
     }
-    return true;
+    if (lo >= 64 && lo < 128) cls |= kClassClose;
+    if (lo < 64) cls |= kClassShort;
+    if (p.mod_depth != 0.0F) cls |= kClassModulated;
+    return cls;
 }
 
-// Speed hint for the steady-state reverb kernel: does any instance of a list have a tap distance of 64..127 samples?
-void rescan_close_taps(oalsfx_batch* b)
+// Host-side belief about which reverb instances the steady-state kernel will fully process: they are listed first and go
+// to that kernel, the others straight to the general kernel (a speed hint; the steady-state kernel decides on the device
+// from the real state and falls back by itself).
+bool reverb_settled(const oalsfx_batch* b, size_t idx)
 {
-    for (int s = 0; s < b->slots; ++s)
-        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) b->close_taps[s][t] = b->short_taps[s][t] = false;
-    for (int i = 0; i < b->n; ++i)
-        for (int s = 0; s < b->slots; ++s) {
-            const oalsfx_slot_params& sp = b->h_params[static_cast<size_t>(i) * b->slots + s];
-            if (sp.type != OALSFX_REVERB && sp.type != OALSFX_EAX_REVERB) continue;
-            const oalsfx_reverb_params& p = sp.u.reverb;
-            int lo = 1 << 30;
-            for (int j = 0; j < 4; ++j)
-                lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
-            if (lo >= 64 && lo < 128) b->close_taps[s][sp.type] = true;
-            if (lo < 64) b->short_taps[s][sp.type] = true;
-            if (p.mod_depth != 0.0F) b->modulated[s][sp.type] = true;
-        }
+    return (b->slot_class[idx] & kClassSteady) != 0 && b->since_update[idx] >= kSettleFrames;
 }
 
-void recount_unsettled(oalsfx_batch* b)
+void reclassify_slot(oalsfx_batch* b, size_t idx, int slot)
 {
-    int before = 0, after = 0;
-    for (int s = 0; s < b->slots; ++s)
-        for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) { before += b->unsettled[s][t]; b->unsettled[s][t] = 0; }
-    for (int i = 0; i < b->n; ++i)
-        for (int s = 0; s < b->slots; ++s) {
-            const size_t idx = static_cast<size_t>(i) * b->slots + s;
-            const int t = b->h_params[idx].type;
-            if ((t == OALSFX_REVERB || t == OALSFX_EAX_REVERB) && !reverb_settled(b, idx)) { b->unsettled[s][t] += 1; ++after; }
-        }
-    if (after != before) b->lists_dirty = true; // the settled-first order of the reverb lists is stale
+    const uint8_t before = b->slot_class[idx], after = classify_slot(b->h_params[idx]);
+    b->n_close[slot] += ((after & kClassClose) != 0) - ((before & kClassClose) != 0);
+    b->n_short[slot] += ((after & kClassShort) != 0) - ((before & kClassShort) != 0);
+    if (after & kClassModulated) b->modulated[slot] = true;
+    b->slot_class[idx] = after;
+}
+
+// After a mix: the slots that were updated recently move towards "steady"; the list order is stale once one arrives.
+void advance_settling(oalsfx_batch* b, int frames)
+{
+    size_t keep = 0;
+    for (size_t k = 0; k < b->settling.size(); ++k) {
+        const size_t idx = b->settling[k];
+        b->since_update[idx] = std::min(b->since_update[idx] + frames, kSettleFrames);
+        if (b->since_update[idx] < kSettleFrames) { b->settling[keep++] = idx; continue; }
+        b->in_settling[idx] = 0;
+        if (b->slot_class[idx] & kClassSteady) b->lists_dirty = true;
+    }
+    b->settling.resize(keep);
 }
 
 // Folds all pending property changes into descriptors, device state and the launch plan: what the
 // reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
 // plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
-bool sync_params(oalsfx_batch* b)
+// Pinned staging buffer for one round of parameter uploads (two take turns; a buffer is reused only after the copy that
+// read it has completed, which by then is two rounds old).
+oalsfx_batch::Stage* acquire_stage(oalsfx_batch* b, size_t bytes)
+{
+    oalsfx_batch::Stage& st = b->stage[b->stage_turn];
+    b->stage_turn ^= 1;
+    if (!st.done && !b->hip_ok(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "hipEventCreate")) return nullptr;
+    if (st.pending) {
+        if (!b->hip_ok(hipEventSynchronize(st.done), "hipEventSynchronize")) return nullptr;
+        st.pending = false;
+    }
+    if (bytes > st.capacity) {
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.dev) (void)hipFree(st.dev);
+        st.host = st.dev = nullptr;
+        st.capacity = 0;
+        const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
+        if (!b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&st.host), cap), "hipHostMalloc(staging)")) return nullptr;
+        if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&st.dev), cap), "hipMalloc(staging)")) return nullptr;
+        st.capacity = cap;
+    }
+    return &st;
+}
+
+// Folds all pending property changes into descriptors, device state and the launch plan: what the
+// reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
+// plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
+// Everything is enqueued on the batch's own stream without waiting for it; `consumer` (the stream the next launches go
+// to) is made to wait for the uploads with an event when it is a different stream.
+bool sync_params(oalsfx_batch* b, hipStream_t consumer)
 {
     if (b->dirty_list.empty() && !b->lists_dirty) return true;
     const size_t total = static_cast<size_t>(b->n) * b->slots;
-    std::vector<uint8_t> up_params(total, 0), up_state(total, 0), up_source(b->n, 0);
     std::map<size_t, int> need; // size class -> slabs needed
     std::vector<size_t> restarted;
+    std::vector<int> up_params, up_state, up_source; // indices of the records to upload
     bool any_type_change = false;
-    bool settle_dirty = false;
+
+    // a caller's stream may still be running kernels that read what is about to be overwritten
+    if (b->last_launch_stream && b->last_launch_stream != b->stream) {
+        if (!b->hip_ok(hipStreamWaitEvent(b->stream, b->ev_mixed, 0), "hipStreamWaitEvent")) return false;
+    }
 
     for (int i : b->dirty_list) {
         InstanceHost& h = b->inst[i];
@@ -260,15 +305,20 @@ bool sync_params(oalsfx_batch* b)
             oalsfx_slot_params& p = b->h_params[idx];
             derive_slot(b->dev, h.active[s], p);
             p.update_seq = ++b->seq[idx];
-            up_params[idx] = 1;
+            up_params.push_back(static_cast<int>(idx));
+            reclassify_slot(b, idx, s);
+            if (b->since_update[idx] >= kSettleFrames) b->lists_dirty = true; // it leaves the believed-steady part of its list
             b->since_update[idx] = 0;
-            settle_dirty = true;
+            if ((b->slot_class[idx] & kClassReverb) && !b->in_settling[idx]) {
+                b->in_settling[idx] = 1;
+                b->settling.push_back(idx);
+            }
             if (h.slot_retyped[s]) {
                 h.slot_retyped[s] = false;
                 any_type_change = true;
                 reset_slot_state(p.type, b->h_state_init[idx]);
                 b->h_state_init[idx].seen_seq = p.update_seq - 1;
-                up_state[idx] = 1;
+                up_state.push_back(static_cast<int>(idx));
                 restarted.push_back(idx);
                 release_slab(b, idx);
                 const size_t floats = static_cast<size_t>(ring_floats_for(p.type, b->rate));
@@ -282,20 +332,21 @@ bool sync_params(oalsfx_batch* b)
         if (updated) {
             int types[OALSFX_MAX_SLOTS] = {};
             for (int s = 0; s < b->slots; ++s) types[s] = static_cast<int>(h.active[s].type_);
-            derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, b->h_source[i]);
-            up_source[i] = 1;
+            oalsfx_source_params& sp = b->h_source[i];
+            auto has_filter = [&](const oalsfx_source_params& x) {
+                int any = x.direct.filter_type;
+                for (int s = 0; s < b->slots; ++s)
+                    if (x.aux[s].out_channels != 0) any |= x.aux[s].filter_type;
+                return any != OALSFX_AF_NONE;
+            };
+            const bool before = has_filter(sp);
+            derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, sp);
+            b->n_filtered += static_cast<int>(has_filter(sp)) - static_cast<int>(before);
+            up_source.push_back(i);
         }
         b->inst_dirty[i] = 0;
     }
     b->dirty_list.clear();
-
-    // send filters: while any instance has one switched on, every mix starts with the filter pre-pass
-    b->filters_active = false;
-    for (int i = 0; i < b->n && !b->filters_active; ++i) {
-        if (b->h_source[i].direct.filter_type != OALSFX_AF_NONE) b->filters_active = true;
-        for (int s = 0; s < b->slots; ++s)
-            if (b->h_source[i].aux[s].filter_type != OALSFX_AF_NONE) b->filters_active = true;
-    }
 
     // ring slabs: grow each size class once, zero fresh chunks in one memset
     for (auto& kv : need) {
@@ -316,6 +367,7 @@ bool sync_params(oalsfx_batch* b)
     bool rings_changed = false;
     for (size_t idx : restarted) {
         const size_t floats = static_cast<size_t>(ring_floats_for(b->h_params[idx].type, b->rate));
+        rings_changed = true; // the slab it held is gone from the table in any case
         if (!floats) continue;
         RingPool& pool = b->pools[floats];
         float* slab = nullptr;
@@ -329,57 +381,81 @@ bool sync_params(oalsfx_batch* b)
         }
         b->h_rings[idx] = slab;
         b->ring_floats[idx] = floats;
-        rings_changed = true;
     }
-    if (rings_changed || !restarted.empty()) {
-        if (!upload_range(b, b->d_rings, b->h_rings.data(), 0, total)) return false;
-    }
-    if (!upload_flagged(b, b->d_params, b->h_params.data(), up_params)) return false;
-    if (!upload_flagged(b, b->d_state, b->h_state_init.data(), up_state)) return false;
-    if (!upload_flagged(b, b->d_source, b->h_source.data(), up_source)) return false;
 
-    if (settle_dirty) recount_unsettled(b); // may flag the list order as stale
-    if (any_type_change || b->lists_dirty) {
-        std::vector<int> lists(total);
+    // ---- the launch plan: one counting sort over the slots of every instance ----
+    const bool rebuild_lists = any_type_change || b->lists_dirty;
+    std::vector<int> lists;
+    if (rebuild_lists) {
+        lists.resize(total);
+        constexpr int kBuckets = OALSFX_REVERB + 4; // ring-light types, then reverb / EAX reverb believed steady, then the other reverbs
         for (int s = 0; s < b->slots; ++s) {
-            int off = 0;
-            auto gather = [&](int t, int want_settled /* -1: any */) {
-                int cnt = 0;
-                for (int i = 0; i < b->n; ++i) {
-                    const size_t idx = static_cast<size_t>(i) * b->slots + s;
-                    if (b->h_params[idx].type != t) continue;
-                    if (want_settled >= 0 && reverb_settled(b, idx) != (want_settled == 1)) continue;
-                    lists[s * b->n + off + cnt++] = i;
-                }
-                off += cnt;
-                return cnt;
+            int count[kBuckets] = {};
+            auto bucket = [&](int i) {
+                const size_t idx = static_cast<size_t>(i) * b->slots + s;
+                const int t = b->h_params[idx].type;
+                if (t < OALSFX_REVERB) return t;
+                return OALSFX_REVERB + (t - OALSFX_REVERB) + (reverb_settled(b, idx) ? 0 : 2);
             };
-            for (int t = 0; t < OALSFX_REVERB; ++t) {
-                b->list_offset[s][t] = s * b->n + off;
-                b->list_count[s][t] = gather(t, -1);
-            }
-            // instances believed steady first: the 4-instance workgroups of the steady-state kernel get homogeneous work and
-            // the rest of both reverb types forms one list for the general kernel; the order has no effect on results
+            for (int i = 0; i < b->n; ++i) count[bucket(i)] += 1;
+            int start[kBuckets];
+            int off = s * b->n;
+            for (int k = 0; k < kBuckets; ++k) { start[k] = off; off += count[k]; }
+            for (int t = 0; t < OALSFX_REVERB; ++t) { b->list_offset[s][t] = start[t]; b->list_count[s][t] = count[t]; }
             for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) {
-                b->list_offset[s][t] = s * b->n + off;
-                b->steady_count[s][t] = gather(t, 1);
+                b->list_offset[s][t] = start[t];
+                b->steady_count[s][t] = count[t];
+                b->list_count[s][t] = count[t] + count[t + 2];
             }
-            b->general_offset[s] = s * b->n + off;
-            b->general_count[s] = 0;
-            for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) {
-                const int g = gather(t, 0);
-                b->general_count[s] += g;
-                b->list_count[s][t] = b->steady_count[s][t] + g;
-            }
+            b->general_offset[s] = start[OALSFX_REVERB + 2];
+            b->general_count[s] = count[OALSFX_REVERB + 2] + count[OALSFX_REVERB + 3];
+            int fill[kBuckets];
+            for (int k = 0; k < kBuckets; ++k) fill[k] = start[k];
+            for (int i = 0; i < b->n; ++i) lists[fill[bucket(i)]++] = i;
         }
-        if (!upload_range(b, b->d_lists, lists.data(), 0, total)) return false;
-        // the upload above reads a local vector: it must finish before the vector dies
-        if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return false;
         b->lists_dirty = false;
     }
-    rescan_close_taps(b);
+
+    // ---- one packed upload: [indices | records] per array, the ring table, the lists ----
+    auto padded = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+    const size_t n_p = up_params.size(), n_s = up_state.size(), n_src = up_source.size();
+    size_t off = 0;
+    const size_t o_pi = off; off += padded(n_p * sizeof(int));
+    const size_t o_pr = off; off += padded(n_p * sizeof(oalsfx_slot_params));
+    const size_t o_si = off; off += padded(n_s * sizeof(int));
+    const size_t o_sr = off; off += padded(n_s * sizeof(oalsfx_slot_state));
+    const size_t o_ci = off; off += padded(n_src * sizeof(int));
+    const size_t o_cr = off; off += padded(n_src * sizeof(oalsfx_source_params));
+    const size_t o_rt = off; off += rings_changed ? padded(total * sizeof(float*)) : 0;
+    const size_t o_li = off; off += rebuild_lists ? padded(total * sizeof(int)) : 0;
+    if (off > 0) {
+        oalsfx_batch::Stage* st = acquire_stage(b, off);
+        if (!st) return false;
+        if (n_p) std::memcpy(st->host + o_pi, up_params.data(), n_p * sizeof(int));
+        for (size_t k = 0; k < n_p; ++k) std::memcpy(st->host + o_pr + k * sizeof(oalsfx_slot_params), &b->h_params[up_params[k]], sizeof(oalsfx_slot_params));
+        if (n_s) std::memcpy(st->host + o_si, up_state.data(), n_s * sizeof(int));
+        for (size_t k = 0; k < n_s; ++k) std::memcpy(st->host + o_sr + k * sizeof(oalsfx_slot_state), &b->h_state_init[up_state[k]], sizeof(oalsfx_slot_state));
+        if (n_src) std::memcpy(st->host + o_ci, up_source.data(), n_src * sizeof(int));
+        for (size_t k = 0; k < n_src; ++k) std::memcpy(st->host + o_cr + k * sizeof(oalsfx_source_params), &b->h_source[up_source[k]], sizeof(oalsfx_source_params));
+        if (rings_changed) std::memcpy(st->host + o_rt, b->h_rings.data(), total * sizeof(float*));
+        if (rebuild_lists) std::memcpy(st->host + o_li, lists.data(), total * sizeof(int));
+        if (!b->hip_ok(hipMemcpyAsync(st->dev, st->host, off, hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(parameters)")) return false;
+        if (!b->hip_ok(hipEventRecord(st->done, b->stream), "hipEventRecord")) return false;
+        st->pending = true;
+        using oalsfx_hip::launch_scatter_records;
+        launch_scatter_records(b->d_params, sizeof(oalsfx_slot_params), st->dev + o_pr, reinterpret_cast<const int*>(st->dev + o_pi), static_cast<int>(n_p), b->stream);
+        launch_scatter_records(b->d_state, sizeof(oalsfx_slot_state), st->dev + o_sr, reinterpret_cast<const int*>(st->dev + o_si), static_cast<int>(n_s), b->stream);
+        launch_scatter_records(b->d_source, sizeof(oalsfx_source_params), st->dev + o_cr, reinterpret_cast<const int*>(st->dev + o_ci), static_cast<int>(n_src), b->stream);
+        if (rings_changed && !b->hip_ok(hipMemcpyAsync(b->d_rings, st->dev + o_rt, total * sizeof(float*), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(ring table)")) return false;
+        if (rebuild_lists && !b->hip_ok(hipMemcpyAsync(b->d_lists, st->dev + o_li, total * sizeof(int), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(lists)")) return false;
+        if (!b->hip_ok(hipGetLastError(), "parameter upload")) return false;
+    }
     // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
-    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
+    if (consumer && consumer != b->stream) {
+        if (!b->hip_ok(hipEventRecord(b->ev_uploaded, b->stream), "hipEventRecord")) return false;
+        if (!b->hip_ok(hipStreamWaitEvent(consumer, b->ev_uploaded, 0), "hipStreamWaitEvent")) return false;
+    }
+    return true;
 }
 
 bool ensure_mixbuf(oalsfx_batch* b)
@@ -440,8 +516,8 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     c.progress = hand_over ? b->d_progress : nullptr;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
-        oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->close_taps[slot][r] || b->close_taps[slot][e],
-                                         b->modulated[slot][r] || b->modulated[slot][e], b->short_taps[slot][r] || b->short_taps[slot][e], stream);
+        oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0, b->modulated[slot],
+                                         b->n_short[slot] > 0, stream);
     }
     if (hand_over) {
         c.frames = ctx.frames;
@@ -483,10 +559,10 @@ int reverb_free_run(const oalsfx_batch* b, int slot)
 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
 {
-    if (!sync_params(b)) return false;
+    if (!sync_params(b, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
     b->timing = b->timing_every > 0 && (b->mix_calls++ % b->timing_every) == 0;
-    const bool filtered = b->filters_active;
+    const bool filtered = b->n_filtered > 0;
     const int chunk_max = std::min(frames, OALSFX_MAX_CHUNK);
     const size_t plane = static_cast<size_t>(b->n) * chunk_max * b->channels;
     if (filtered && plane > b->filtered_capacity) {
@@ -581,12 +657,9 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         }
         done += n;
     }
-    bool any = false;
-    for (int s = 0; s < b->slots && !any; ++s) any = b->unsettled[s][OALSFX_REVERB] || b->unsettled[s][OALSFX_EAX_REVERB];
-    if (any) {
-        for (int& f : b->since_update) f = std::min(f + frames, kSettleFrames);
-        recount_unsettled(b);
-    }
+    advance_settling(b, frames);
+    b->last_launch_stream = stream;
+    if (stream != b->stream && !b->hip_ok(hipEventRecord(b->ev_mixed, stream), "hipEventRecord")) return false;
     return b->hip_ok(hipGetLastError(), "kernel launch");
 }
 
@@ -633,11 +706,15 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->h_rings.assign(total, nullptr);
     b->ring_floats.assign(total, 0);
     b->inst_dirty.assign(n_instances, 0);
+    b->touched.assign(n_instances, 0);
     b->since_update.assign(total, 0);
+    b->slot_class.assign(total, 0);
+    b->in_settling.assign(total, 0);
     for (int i = 0; i < n_instances; ++i) {
         b->inst[i].initialize(effect_count);
         mark_dirty(b, i);
     }
+    mark_touched(b, 0, n_instances);
 
     bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     for (int k = 0; k < kSideStreams; ++k) {
@@ -645,6 +722,8 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
         ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming), "hipEventCreate");
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_uploaded, hipEventDisableTiming), "hipEventCreate");
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_mixed, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_params), total * sizeof(oalsfx_slot_params)), "hipMalloc(params)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_slot_state)), "hipMalloc(state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
@@ -691,6 +770,13 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
         if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);
     }
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
+    if (b->ev_uploaded) hipEventDestroy(b->ev_uploaded);
+    if (b->ev_mixed) hipEventDestroy(b->ev_mixed);
+    for (auto& st : b->stage) {
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.dev) (void)hipFree(st.dev);
+        if (st.done) hipEventDestroy(st.done);
+    }
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
 }
@@ -708,6 +794,7 @@ int oalsfx_batch_set_effect(oalsfx_batch* b, int first, int count, int slot, con
     const auto* base = reinterpret_cast<const unsigned char*>(effects);
     for (int i = 0; i < count; ++i)
         std::memcpy(&b->inst[first + i].deferred[slot], base + static_cast<size_t>(i) * stride_bytes, sizeof(oalsfx_effect));
+    mark_touched(b, first, count);
     return 1;
 }
 
@@ -716,6 +803,7 @@ int oalsfx_batch_set_effect_type(oalsfx_batch* b, int first, int count, int slot
     if (!range_ok(b, first, count)) return 0;
     if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
     for (int i = 0; i < count; ++i) b->inst[first + i].deferred[slot].set_type_and_defaults(static_cast<oalsfxpp::EffectType>(effect_type));
+    mark_touched(b, first, count);
     return 1;
 }
 
@@ -726,6 +814,7 @@ int oalsfx_batch_set_effect_props(oalsfx_batch* b, int first, int count, int slo
     const auto* base = static_cast<const unsigned char*>(props);
     for (int i = 0; i < count; ++i)
         std::memcpy(&b->inst[first + i].deferred[slot].props_, base + static_cast<size_t>(i) * stride_bytes, sizeof(oalsfxpp::EffectProps));
+    mark_touched(b, first, count);
     return 1;
 }
 
@@ -741,6 +830,7 @@ int oalsfx_batch_set_send_props(oalsfx_batch* b, int first, int count, int slot,
         if (slot < 0) h.direct_deferred = p;
         else h.aux_props[slot] = p;
     }
+    mark_touched(b, first, count);
     return 1;
 }
 
@@ -764,13 +854,23 @@ int oalsfx_batch_get_send_props(const oalsfx_batch* b, int instance, int slot, i
 int oalsfx_batch_apply_changes(oalsfx_batch* b, int first, int count)
 {
     if (!range_ok(b, first, count)) return 0;
-    for (int i = first; i < first + count; ++i) {
+    size_t kept = 0;
+    for (size_t k = 0; k < b->touched_list.size(); ++k) {
+        const int i = b->touched_list[k];
+        if (i < first || i >= first + count) { b->touched_list[kept++] = i; continue; }
         InstanceHost& h = b->inst[i];
         h.apply_changes();
         bool dirty = h.source_changed;
         for (int s = 0; s < b->slots; ++s) dirty |= h.slot_changed[s];
         if (dirty) mark_dirty(b, i);
+        // An auxiliary send whose properties were ever set differs from its never-written deferred copy for good, and the
+        // reference then recomputes that source on every apply (src/oalsfxpp.cpp:3772-3780): such an instance stays listed.
+        bool sticky = false;
+        for (int s = 0; s < b->slots; ++s) sticky |= !oalsfxpp::SendProps::are_equal(h.aux_props[s], h.aux_deferred[s]);
+        if (sticky) b->touched_list[kept++] = i;
+        else b->touched[i] = 0;
     }
+    b->touched_list.resize(kept);
     return 1;
 }
 
@@ -818,7 +918,7 @@ int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_
 {
     if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return b->fail(kErrRange) ? 1 : 0;
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
-    if (!sync_params(b)) return 0;
+    if (!sync_params(b, nullptr)) return 0;
     const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
     if (params) *params = b->h_params[idx];
     if (state) {
@@ -831,7 +931,7 @@ int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_
 int oalsfx_batch_read_ring(oalsfx_batch* b, int instance, int slot, float* out, int max_floats)
 {
     if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
-    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b)) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
     const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
     const int floats = static_cast<int>(b->ring_floats[idx]);
     if (out && floats) {
@@ -846,7 +946,7 @@ int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params
 {
     if (instance < 0 || instance >= b->n) return b->fail(kErrRange) ? 1 : 0;
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
-    if (!sync_params(b)) return 0;
+    if (!sync_params(b, nullptr)) return 0;
     if (params) *params = b->h_source[instance];
     if (state) {
         if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;

@@ -64,6 +64,8 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const i
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
                          hipStream_t stream);
+// record k of `packed` (count records of record_bytes, a multiple of 4) goes to slot indices[k] of the device array `dst`
+void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, const int* indices, int count, hipStream_t stream);
 void launch_null(hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream);

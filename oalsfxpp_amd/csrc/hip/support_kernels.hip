@@ -91,6 +91,23 @@ void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, u
     hipLaunchKernelGGL(k_fill_synthetic, dim3((instances + 63) / 64), dim3(64), 0, stream, dst, instances, floats_per_instance, buffer_index);
 }
 
+// ---- parameter uploads: record k of a packed array goes to slot indices[k] of a device array (one 64-lane group per record)
+__global__ __launch_bounds__(64) void k_scatter_records(unsigned* __restrict__ dst, int record_dwords, const unsigned* __restrict__ packed,
+                                                        const int* __restrict__ indices, int count)
+{
+    const int k = blockIdx.x;
+    if (k >= count) return;
+    const size_t to = static_cast<size_t>(indices[k]) * record_dwords, from = static_cast<size_t>(k) * record_dwords;
+    for (int i = threadIdx.x; i < record_dwords; i += 64) dst[to + i] = packed[from + i];
+}
+
+void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, const int* indices, int count, hipStream_t stream)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_scatter_records, dim3(count), dim3(64), 0, stream, static_cast<unsigned*>(dst), static_cast<int>(record_bytes / 4),
+                       static_cast<const unsigned*>(packed), indices, count);
+}
+
 // ---- an empty kernel: what an event pair around a launch measures beyond the kernel itself ----
 __global__ void k_null() {}
 

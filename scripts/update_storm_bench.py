@@ -1,0 +1,34 @@
+"""Step time when a fraction of the instances gets a new preset before every buffer (4096 EAX reverbs, stereo, 256 frames)."""
+import random, sys, time
+sys.path.insert(0, ".")
+import torch
+from oalsfxpp_amd import desc, lib
+from oalsfxpp_amd.api import Batch
+n, frames = 4096, 256
+b = Batch(n, desc.FMT_STEREO, 48000, 1)
+b.set_effect_type(0, desc.EAX_REVERB); b.apply_changes()
+src = torch.empty(n * frames * 2, device="cuda").uniform_(-1, 1); dst = torch.empty_like(src)
+presets = []
+for i in range(113):
+    e = lib.effect_defaults(desc.EAX_REVERB); e.props.reverb = lib.preset(i)[1]; presets.append(e)
+rng = random.Random(1)
+levels = [int(a) for a in sys.argv[1:]] or [0, 4, 40, 204, 1024]
+for k in levels:
+    for _ in range(8):   # untimed: the same update rate, so that staging buffers have their size
+        for i in rng.sample(range(n), k):
+            b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
+        if k: b.apply_changes()
+        b.mix_device(frames, src.data_ptr(), dst.data_ptr())
+    b.synchronize()
+    t_upd = 0.0
+    t0 = time.perf_counter()
+    for step in range(50):
+        u0 = time.perf_counter()
+        for i in rng.sample(range(n), k):
+            b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
+        if k: b.apply_changes()
+        t_upd += time.perf_counter() - u0
+        b.mix_device(frames, src.data_ptr(), dst.data_ptr())
+    b.synchronize()
+    dt = (time.perf_counter() - t0) / 50
+    print(f"{k:5d} updates per buffer: step {dt*1e6:8.1f} us (of which the setter calls from Python {t_upd/50*1e6:8.1f} us)", flush=True)
