@@ -137,6 +137,9 @@ def ref_lib():
         lib.ref_mix.argtypes = [C.c_void_p, C.c_int, _fp, _fp]
         lib.ref_error.restype = C.c_char_p
         lib.ref_error.argtypes = [C.c_void_p]
+        if hasattr(lib, "ref_bench"):
+            lib.ref_bench.restype = C.c_double
+            lib.ref_bench.argtypes = [C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 5
         lib.ref_effect_defaults.argtypes = [C.c_int, C.c_void_p]
         lib.ref_effect_normalize.argtypes = [C.c_void_p]
         lib.ref_preset_name.restype = C.c_char_p

@@ -13,6 +13,9 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -355,6 +358,55 @@ int ref_dump_ring(void* h, int idx, int r, float* out)
     default:
         return 0;
     }
+}
+
+// cpu_baseline (kind "reference"): n_instances reference Api objects, each with `effect` in slot 0, fed the synthetic
+// input of SURVEY 8d (same generator as oracle_synth / k_fill_synthetic) for warmup + buffers calls of Api::mix on
+// `threads` host threads over a dynamic partition of the instances.  Returns the seconds the timed buffers took.
+double ref_bench(int channel_format, int rate, const void* effect, int n_instances, int frames, int warmup, int buffers, int threads)
+{
+    std::vector<std::unique_ptr<Api>> inst(n_instances);
+    int channels = 0;
+    for (auto& p : inst) {
+        p.reset(new Api{});
+        if (!p->initialize(static_cast<ChannelFormat>(channel_format), rate, 1)) return -1.0;
+        Effect e;
+        std::memcpy(&e, effect, sizeof(Effect));
+        p->set_effect(0, e);
+        p->apply_changes();
+        channels = p->get_channel_count();
+    }
+    auto synth = [](uint32_t instance, uint32_t buffer_index, float* out, int count) {
+        uint32_t x = 0x9E3779B9u ^ (instance * 2654435761u) ^ buffer_index;
+        if (x == 0) x = 1;
+        for (int i = 0; i < count; ++i) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            out[i] = static_cast<float>(x >> 8) * (1.0F / 8388608.0F) - 1.0F;
+        }
+    };
+    auto run = [&](int first_buf, int count) {
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            std::vector<float> src(static_cast<size_t>(frames) * channels), dst(src.size());
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n_instances) break;
+                for (int b = 0; b < count; ++b) {
+                    synth(static_cast<uint32_t>(i), static_cast<uint32_t>(first_buf + b), src.data(), static_cast<int>(src.size()));
+                    inst[i]->mix(frames, src.data(), dst.data());
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    };
+    run(0, warmup);
+    const auto t0 = std::chrono::steady_clock::now();
+    run(warmup, buffers);
+    const auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
 }
 
 } // extern "C"
