@@ -214,7 +214,8 @@ def main():
     # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
     kernels = {}
     timed = {"wave_effects (all ring-light types of a slot, one launch)": desc.CHORUS, "reverb + eax_reverb steady-state": desc.EAX_REVERB,
-             "reverb + eax_reverb general": desc.REVERB + 16}
+             "reverb + eax_reverb general": desc.REVERB + 16,
+             "slot_mixed (ring-light types + steady reverbs of a slot, one grid)": 32}
     for name, t in timed.items():
         l, ms = batch.kernel_timing_read(t)
         if l:

@@ -95,7 +95,8 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
  * timed call are bracketed by a start / stop event pair; read() returns the number of launches of `effect_type`
  * since enable and their summed duration in milliseconds.  Every effect type of a slot other than the two reverbs shares
  * one launch (k_wave_effects), which any of those types reads.  The two reverb types share their launches too: either
- * type reads the steady-state kernel, type + 16 the general kernel (the groups of a slot run side by side). */
+ * type reads the steady-state kernel, type + 16 the general kernel (the groups of a slot run side by side).  32 reads the
+ * grid that serves a slot's ring-light effects and steady reverbs together (k_slot_mixed: mono / stereo, whole tiles). */
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
 /* What such an event pair measures beyond the kernel: the average elapsed time of `repeats` pairs with nothing between them

@@ -468,7 +468,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 int debug_flags()
 {
     // timing experiments only (OALSFX_DEBUG_FLAGS): 8 every reverb through the general kernel, 32 / 64 tap distances rounded
-    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams
+    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two launches)
     static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
     return v;
 }
@@ -496,6 +496,7 @@ struct ScopedTiming {
 constexpr size_t kTimelineBytes = (64 * 4 + 64) * 96 * sizeof(unsigned long long); // 64 sampled workgroups x 4 waves x 96 stamps (steady-state kernel) + 64 sampled instances x 96 (general path)
 constexpr int kTimedGeneralOffset = 16; // TimedLaunch::type of a reverb type's general-kernel launches
 constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch for the ring-light effect types
+constexpr int kTimedMixed = -2;       // ... of the grid that serves ring-light effects and steady reverbs of a slot together
 
 // Can the steady-state kernel be used for this chunk at all?
 bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 64 && !(debug_flags() & 8); }
@@ -547,6 +548,21 @@ void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     if (count == 0) return;
     ScopedTiming timing(b, kTimedWaveEffects, stream);
     oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, flags, stream);
+}
+
+// Ring-light effects and believed-steady reverbs of one slot in one grid (k_slot_mixed).
+void launch_mixed_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+{
+    const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
+    const int first_type = null_has_duty ? OALSFX_NULL : OALSFX_NULL + 1;
+    int light = 0;
+    for (int t = first_type; t < OALSFX_REVERB; ++t) light += b->list_count[slot][t];
+    const int steady = b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB];
+    KernelCtx c = ctx;
+    c.progress = nullptr; // an instance that turns out not to be steady falls back inside the grid
+    ScopedTiming timing(b, kTimedMixed, stream);
+    oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->list_offset[slot][OALSFX_REVERB], steady, b->d_lists + b->list_offset[slot][first_type], light,
+                                  flags, stream);
 }
 
 // Number of consecutive slots from `slot` on that hold no reverb at all: such a run is one fused launch over every instance.
@@ -626,7 +642,10 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             const bool use_steady = steady_kernel_usable(ctx);
             const int rs = use_steady ? b->steady_count[s][OALSFX_REVERB] : 0, es = use_steady ? b->steady_count[s][OALSFX_EAX_REVERB] : 0;
             const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
-            const bool part_on[3] = {light > 0, rs + es > 0, reverbs - rs - es > 0};
+            bool part_on[3] = {light > 0, rs + es > 0, reverbs - rs - es > 0};
+            // ring-light effects and steady reverbs in the same slot (mono / stereo, whole tiles): one grid serves both
+            const bool mixed = part_on[0] && part_on[1] && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline && !(debug_flags() & 0x80000);
+            if (mixed) part_on[0] = false; // part 1 below launches the grid that does both
             int parts = 0;
             for (bool on : part_on) parts += on;
             const bool fork = parts > 1 && !(debug_flags() & 0x20000);
@@ -642,6 +661,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 }
                 if (g == 0) {
                     launch_wave_group(b, ctx, s, flags, gs);
+                } else if (g == 1 && mixed) {
+                    launch_mixed_part(b, ctx, s, flags, gs);
                 } else if (g == 1) {
                     launch_reverb_steady_part(b, ctx, s, flags, gs);
                 } else {
@@ -988,6 +1009,7 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     // the two reverb types share their launches
     if (key == OALSFX_REVERB) key = OALSFX_EAX_REVERB;
     if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset;
+    if (effect_type == 32) key = kTimedMixed;
     for (auto& t : b->timed) {
         if (t.type != key) continue;
         if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return 0;

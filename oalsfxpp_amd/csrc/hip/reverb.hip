@@ -29,6 +29,7 @@
 #include <float.h>
 
 #include "common.hpp"
+#include "wave_effects_body.hpp"
 
 namespace oalsfx_hip {
 
@@ -230,30 +231,43 @@ __device__ __forceinline__ void lds_barrier()
 // (its LDS would have to be sized for the general path's 64 gain ramps) but left, through ctx.progress, to the general
 // kernel that the host launches right after on the same list.  The mono / stereo builds work the same way when the host
 // hands them the whole tiles of a ragged chunk (ctx.progress set): the general kernel then finishes every instance.
+// LDS of one workgroup of the cooperative kernel
+template <int CH, int NW>
+struct SteadyShared {
+    static constexpr bool MC = CH > 2;
+    static constexpr int kMcBase = ut::SIZE + 64 + 8 * kRow; // multichannel tables behind the modulation row and the hand-over rows:
+                                                             // GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
+    // mono / stereo: sized for the general path, which non-steady instances fall back to
+    static constexpr int kFloats = MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
+    alignas(16) float lds_all[NW][kFloats];
+    float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
+    int go_all[NW];
+    int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
+};
+
+// The work of workgroup `group` of the cooperative kernel (its own kernel below; also one half of k_slot_mixed).
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
-__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
+                                                    SteadyShared<CH, NW>& sh)
 {
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
     int ts_i = 0;
     auto stamp = [&]() {
-        if (TL && (blockIdx.x & 63) == 0 && (threadIdx.x & 63) == 0 && ts_i < 96)
-            ctx.timeline[((blockIdx.x >> 6) * NW + (threadIdx.x >> 6)) * 96 + ts_i++] = clock64();
+        if (TL && (group & 63) == 0 && (threadIdx.x & 63) == 0 && ts_i < 96)
+            ctx.timeline[((group >> 6) * NW + (threadIdx.x >> 6)) * 96 + ts_i++] = clock64();
     };
     stamp();
     static_assert(CH <= 2 || CH == 8, "mono, stereo, or the multichannel build");
     constexpr bool MC = CH > 2;
-    constexpr int kMcBase = ut::SIZE + 64 + 8 * kRow; // multichannel tables behind the modulation row and the hand-over rows:
-                                                      // GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
-    // mono / stereo: sized for the general path, which non-steady instances fall back to below
-    constexpr int kFloats = MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
+    constexpr int kMcBase = SteadyShared<CH, NW>::kMcBase;
     const int nch = MC ? ctx.channels : CH;
-    __shared__ __attribute__((aligned(16))) float lds_all[NW][kFloats];
-    __shared__ float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
-    __shared__ int go_all[NW];
-    __shared__ int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
+    auto& lds_all = sh.lds_all;
+    auto& chain_all = sh.chain_all;
+    auto& go_all = sh.go_all;
+    auto& eax_all = sh.eax_all;
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x * NW + wib;
+    const int w = group * NW + wib;
     const bool valid = w < count;
     const int lane = threadIdx.x & 63;
     const int frames = ctx.frames;
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
     const bool chain2_on = chain_on && eax_all[cw] != 0;
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
     // put the same phase on the same SIMD
-    const int duty = (wib - static_cast<int>(blockIdx.x)) & (NW - 1);
+    const int duty = (wib - group) & (NW - 1);
 
     const int tiles = any_go ? frames >> 6 : 0; // a workgroup without a steady instance skips the cooperative loop altogether
     for (int tile = 0; tile < tiles; ++tile) {
@@ -869,6 +883,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
         }
     }
     stamp(); // state handed back
+}
+
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
+__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+{
+    __shared__ SteadyShared<CH, NW> sh;
+    reverb_steady_group<CH, NW, TL, HY, MD, ST>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1467,6 +1488,41 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
     if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     reverb_general_instance<CH>(ctx, slot, inst, flags, lds_all[wave_in_block], lane);
+}
+
+// A slot that holds ring-light effects for some instances and steady reverbs for others (BASELINE configs[3]): one grid.  The
+// first workgroups are groups of the cooperative reverb kernel (its most general build: the reverbs of such a batch rarely
+// share properties), the others run one ring-light instance per wavefront.  Two launches on two streams do the same work
+// concurrently, but ordering them against the caller's stream costs ~7 us at the fork and ~20 us at the join on this stack.
+template <int CH>
+__global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, const int* __restrict__ steady_list, int steady_count,
+                                                       const int* __restrict__ light_list, int light_count, int flags)
+{
+    union Shared {
+        SteadyShared<CH, 4> steady;
+        float light[4][wfx::kLdsFloats];
+    };
+    __shared__ Shared sh;
+    const int steady_groups = (steady_count + 3) >> 2;
+    const int group = static_cast<int>(blockIdx.x);
+    if (group < steady_groups) {
+        reverb_steady_group<CH, 4, false, true, true, true>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
+        return;
+    }
+    const int wib = threadIdx.x >> 6;
+    const int w = (group - steady_groups) * 4 + wib;
+    if (w >= light_count) return; // whole wavefronts leave; this half has no workgroup barrier
+    const int inst = __builtin_amdgcn_readfirstlane(light_list[w]);
+    wfx::wave_slots<CH>(ctx, slot, 1, inst, flags, sh.light[wib], threadIdx.x & 63);
+}
+
+void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count, int flags,
+                       hipStream_t stream)
+{
+    if (ctx.frames <= 0 || steady_count + light_count <= 0) return;
+    const dim3 grid((steady_count + 3) / 4 + (light_count + 3) / 4), block(256);
+    if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, flags);
+    else OALSFX_LAUNCH((k_slot_mixed<2>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, flags);
 }
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to

@@ -1,674 +1,7 @@
-// Process kernel for the ring-light effects: null, chorus, flanger, compressor, dedicated, distortion, echo,
-// equalizer, ring modulator -- one wavefront per instance, lanes = 64 consecutive sample times (a tile).
-//
-// Each body replaces the matching EffectState::do_process of the reference (line ranges at each struct).  What is
-// parallel over the 64 lanes: the send mix, everything pointwise (wave shapers, carriers, LFOs, panning) and every
-// delay-line access whose source lies before the tile.  What stays serial, because it must round exactly like the
-// reference: the feedback half of each biquad and the compressor's gain follower run on one "chain" lane per signal
-// over an LDS row; delay lines with feedback shorter than a tile are cut into sub-blocks no longer than the delay.
-//
-// One launch serves every instance of a slot whatever its type (a wave-uniform switch on the descriptor's type), so
-// a batch with many effect types mixed (BASELINE configs[3]) still fills the chip with a single grid.
-//
-// LDS rows are 4 + 64 floats: row[2], row[3] hold the two samples before the tile (the filter history), row[4 + i]
-// sample i of the tile; after a tile the last two samples move into the prefix.
-#include "common.hpp"
+// The ring-light effects' own kernel: one wavefront per listed instance (bodies in wave_effects_body.hpp).
+#include "wave_effects_body.hpp"
 
 namespace oalsfx_hip {
-
-namespace {
-
-constexpr int kRow = 68;
-constexpr int kLdsRows = 20;                  // equalizer: 5 stages x 4 B-format channels
-constexpr int kLdsFloats = kLdsRows * kRow;   // distortion needs 3 x (4 + 256)
-
-typedef __attribute__((address_space(1))) float GlobalFloat;
-// Parameters are read through the constant address space: scalar loads, hoisted out of the tile loop.
-typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
-
-struct Coef { float b0, b1, b2, a1, a2; };
-template <class B> __device__ __forceinline__ Coef coef(const B& b) { return Coef{b.b0, b.b1, b.b2, b.a1, b.a2}; }
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Feedback half of a biquad over entries [lo, hi) of a row that holds the feed-forward sums; outputs replace them.
-// y = (u - a1*y1) - a2*y2 (reference FilterState::process, src/oalsfxpp.cpp:1009-1014).  row[lo + 3], row[lo + 2] hold
-// the two outputs before `lo`.
-__device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a1, float a2)
-{
-    float y1 = row[4 + lo - 1], y2 = row[4 + lo - 2];
-    int i = lo;
-    if ((lo & 3) == 0 && lo + 4 <= hi) {
-        // the next four sums are requested before the current four are worked on: the LDS latency hides behind the
-        // dependent arithmetic instead of adding to it
-        float4 u = *reinterpret_cast<const float4*>(row + 4 + lo);
-        for (; i + 4 <= hi; i += 4) {
-            float4 un = u;
-            if (i + 8 <= hi) un = *reinterpret_cast<const float4*>(row + 8 + i);
-            float4 y;
-            y.x = (u.x - (a1 * y1)) - (a2 * y2);
-            y.y = (u.y - (a1 * y.x)) - (a2 * y1);
-            y.z = (u.z - (a1 * y.y)) - (a2 * y.x);
-            y.w = (u.w - (a1 * y.z)) - (a2 * y.y);
-            *reinterpret_cast<float4*>(row + 4 + i) = y;
-            y2 = y.z;
-            y1 = y.w;
-            u = un;
-        }
-    }
-    for (; i < hi; ++i) {
-        const float y = (row[4 + i] - (a1 * y1)) - (a2 * y2);
-        row[4 + i] = y;
-        y2 = y1;
-        y1 = y;
-    }
-}
-
-// Moves the last two of the n samples a row received into its history prefix.
-__device__ __forceinline__ void advance_row(float* row, int n)
-{
-    if (n >= 2) {
-        const float a = row[4 + n - 2], b = row[4 + n - 1];
-        row[2] = a; row[3] = b;
-    } else if (n == 1) {
-        row[2] = row[3]; row[3] = row[4];
-    }
-}
-
-__device__ __forceinline__ void load_hist(float* xrow, float* yrow, const oalsfx_hist_t& h)
-{
-    xrow[2] = h.x[1]; xrow[3] = h.x[0];
-    yrow[2] = h.y[1]; yrow[3] = h.y[0];
-}
-
-__device__ __forceinline__ void store_hist(const float* xrow, const float* yrow, oalsfx_hist_t& h)
-{
-    h.x[1] = xrow[2]; h.x[0] = xrow[3];
-    h.y[1] = yrow[2]; h.y[0] = yrow[3];
-}
-
-// What a body sees of its instance.
-struct Inst {
-    ConstSlotParams* sp;
-    oalsfx_slot_state* ss;
-    GlobalFloat* ring;
-    float* lds;
-    int lane;
-    int channels;
-};
-
-// std::max / std::min as the reference uses them (first argument wins when the comparison is false, NaNs included)
-__device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
-__device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
-
-template <int CH, class G>
-__device__ __forceinline__ void pan(float out[CH], int channels, const G& gains, float v)
-{
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const float g = gains[c];
-        if (c < channels && audible(g)) out[c] += g * v;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-struct NullW {
-    __device__ void init(const Inst&) {}
-    template <int CH> __device__ void tile(const Inst&, const float*, float*, int) {}
-    __device__ void finish(const Inst&) {}
-};
-
-// dedicated dialog / LFE (reference src/oalsfxpp.cpp:4556-4576)
-struct DedicatedW {
-    __device__ void init(const Inst&) {}
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int)
-    {
-        const auto& p = I.sp->u.dedicated;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const float g = p.gains[c];
-            if (c < I.channels && audible(g)) out[c] += wet[0] * g;
-        }
-    }
-    __device__ void finish(const Inst&) {}
-};
-
-// chorus / flanger (reference src/oalsfxpp.cpp:4113-4276, 5384-5547): buf[o] = in; t = buf[o - d] * feedback; buf[o] += t; out = t
-struct ModDelayW {
-    int offset;
-    __device__ void init(const Inst& I) { offset = I.ss->u.moddelay.offset; }
-    template <class P> __device__ static int lfo_delay(const P& p, int phase)
-    {
-        if (p.waveform == 1) return static_cast<int>((1.0F - fabsf(2.0F - (p.lfo_scale * phase))) * p.depth) + p.delay;
-        return static_cast<int>(glibc_sinf(p.lfo_scale * phase) * p.depth) + p.delay;
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.moddelay;
-        const int lane = I.lane;
-        const unsigned mask = static_cast<unsigned>(p.ring_len - 1);
-        const int o = offset + lane;
-        const float in = wet[0];
-        const float fb = p.feedback;
-        float t[2];
-        // Sample i reads what sample i - d wrote (d == 0: its own input).  Sources before the tile come from the ring in one
-        // round of loads for both sides; sources inside the tile are handed from lane to lane, the lanes whose source is
-        // settled going together.  The tile's 64 new ring values per side are stored once, at the end.
-        int d[2];
-        bool inside[2];
-        float v[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
-            d[k] = lfo_delay(p, phase);
-            inside[k] = d[k] > 0 && lane - d[k] >= 0; // written by an earlier lane of this tile
-            v[k] = in;
-            if (lane < L && d[k] != 0 && !inside[k]) v[k] = buf[static_cast<unsigned>(o - d[k]) & mask];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            float val = 0.0F; // what this lane's sample leaves in the ring
-            t[k] = 0.0F;
-            for (int s = 0; s < L;) {
-                const bool pending = lane >= s && lane < L;
-                const bool blocked = pending && inside[k] && lane - d[k] >= s;
-                const unsigned long long nb = __ballot(blocked);
-                const int e = nb ? static_cast<int>(__builtin_ctzll(nb)) : L;
-                const float handed = __shfl(val, inside[k] ? lane - d[k] : lane);
-                if (pending && lane < e) {
-                    if (inside[k]) v[k] = handed;
-                    t[k] = v[k] * fb;
-                    val = in + t[k];
-                }
-                s = e;
-            }
-            if (lane < L) buf[static_cast<unsigned>(o) & mask] = val;
-        }
-        // left tap before right tap for every output (reference :4193-4208)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) pan<CH>(out, I.channels, p.gains[k], t[k]);
-        // `out += t * g` in the reference; the product commutes
-        offset += L;
-        wave_sync();
-    }
-    __device__ void finish(const Inst& I)
-    {
-        if (I.lane == 0) I.ss->u.moddelay.offset = offset;
-    }
-};
-
-// compressor (reference src/oalsfxpp.cpp:4352-4453)
-struct CompressorW {
-    __device__ void init(const Inst& I)
-    {
-        if (I.lane == 0) I.lds[3] = I.ss->u.compressor.gain_control;
-        wave_sync();
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.compressor;
-        float* row = I.lds;
-        float amplitude = 1.0F;
-        if (p.enabled) {
-            amplitude = fabsf(wet[0]);
-            amplitude = std_max(amplitude + fabsf(wet[1]), std_max(amplitude + fabsf(wet[2]), amplitude + fabsf(wet[3])));
-        }
-        row[4 + I.lane] = amplitude;
-        wave_sync();
-        if (I.lane == 0) {
-            // the gain follower is a serial min/max recurrence (reference :4385-4400)
-            float gc = row[3];
-            const float attack = p.attack_rate, release = p.release_rate;
-            auto follow = [&](float a) {
-                if (a > gc) gc = std_min(gc + attack, a);
-                else if (a < gc) gc = std_max(gc - release, a);
-                return gc;
-            };
-            int i = 0;
-            if (L >= 4) {
-                float4 a = *reinterpret_cast<const float4*>(row + 4); // one request ahead of the dependent arithmetic
-                for (; i + 4 <= L; i += 4) {
-                    float4 an = a;
-                    if (i + 8 <= L) an = *reinterpret_cast<const float4*>(row + 8 + i);
-                    float4 g;
-                    g.x = follow(a.x); g.y = follow(a.y); g.z = follow(a.z); g.w = follow(a.w);
-                    *reinterpret_cast<float4*>(row + 4 + i) = g;
-                    a = an;
-                }
-            }
-            for (; i < L; ++i) row[4 + i] = follow(row[4 + i]);
-            row[3] = gc;
-        }
-        wave_sync();
-        const float output = 1.0F / std_min(2.0F, std_max(0.5F, row[4 + I.lane])); // Math::clamp(gc, 0.5, 2) = min(max_value, max(min_value, gc))
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pan<CH>(out, I.channels, p.gains[j], wet[j] * output);
-    }
-    __device__ void finish(const Inst& I)
-    {
-        if (I.lane == 0) I.ss->u.compressor.gain_control = I.lds[3];
-    }
-};
-
-// equalizer (reference src/oalsfxpp.cpp:5161-5213): four cascaded biquads on each B-format channel.
-// Row (stage * 4 + channel): stage 0 the input, stage b + 1 the output of band b.
-struct EqualizerW {
-    __device__ void init(const Inst& I)
-    {
-        const oalsfx_equalizer_state& s = I.ss->u.equalizer;
-        if (I.lane < 16) {
-            const int b = I.lane >> 2, ch = I.lane & 3;
-            load_hist(I.lds + (b * 4 + ch) * kRow, I.lds + ((b + 1) * 4 + ch) * kRow, s.hist[b][ch]);
-        }
-        wave_sync();
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.equalizer;
-        const int lane = I.lane;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) I.lds[ch * kRow + 4 + lane] = wet[ch];
-        wave_sync();
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const Coef c = coef(p.band[b]);
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                const float* x = I.lds + (b * 4 + ch) * kRow + 4 + lane;
-                I.lds[((b + 1) * 4 + ch) * kRow + 4 + lane] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
-            }
-            wave_sync();
-            if (lane < 4) chain_biquad(I.lds + ((b + 1) * 4 + lane) * kRow, 0, L, c.a1, c.a2);
-            wave_sync();
-        }
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) pan<CH>(out, I.channels, p.gains[ch], I.lds[(16 + ch) * kRow + 4 + lane]);
-        wave_sync();
-        if (lane < 20) advance_row(I.lds + lane * kRow, L);
-        wave_sync();
-    }
-    __device__ void finish(const Inst& I)
-    {
-        oalsfx_equalizer_state& s = I.ss->u.equalizer;
-        if (I.lane < 16) {
-            const int b = I.lane >> 2, ch = I.lane & 3;
-            store_hist(I.lds + (b * 4 + ch) * kRow, I.lds + ((b + 1) * 4 + ch) * kRow, s.hist[b][ch]);
-        }
-    }
-};
-
-// ring modulator (reference src/oalsfxpp.cpp:5652-5784): one-pole high-pass per B-format channel, times the carrier.
-// Rows 0..3 input, 4..7 filter output.
-struct RingModW {
-    int index;
-    __device__ void init(const Inst& I)
-    {
-        const oalsfx_ringmod_state& s = I.ss->u.ringmod;
-        index = s.index;
-        if (I.lane < 4) load_hist(I.lds + I.lane * kRow, I.lds + (4 + I.lane) * kRow, s.hist[I.lane]);
-        wave_sync();
-    }
-    __device__ static float carrier(int waveform, int idx)
-    {
-        constexpr int frac_bits = 24;
-        constexpr int frac_one = 1 << frac_bits;
-        if (waveform == 0) return glibc_sinf(idx * (6.28318530717958647692F / frac_one) - 3.14159265358979323846F) * 0.5F + 0.5F;
-        if (waveform == 1) return static_cast<float>(idx) / frac_one;
-        return static_cast<float>((idx >> (frac_bits - 1)) & 1);
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.ringmod;
-        const int lane = I.lane;
-        const Coef c = coef(p.filter);
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) I.lds[ch * kRow + 4 + lane] = wet[ch];
-        wave_sync();
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            const float* x = I.lds + ch * kRow + 4 + lane;
-            I.lds[(4 + ch) * kRow + 4 + lane] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
-        }
-        wave_sync();
-        if (lane < 4) chain_biquad(I.lds + (4 + lane) * kRow, 0, L, c.a1, c.a2);
-        wave_sync();
-        // the carrier index is pre-incremented: sample i sees index + (i + 1) * step (reference :5748-5752)
-        const unsigned frac_mask = (1u << 24) - 1u;
-        const int idx = static_cast<int>((static_cast<unsigned>(index) + static_cast<unsigned>(lane + 1) * static_cast<unsigned>(p.step)) & frac_mask);
-        const float m = carrier(p.waveform, idx);
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) pan<CH>(out, I.channels, p.gains[ch], I.lds[(4 + ch) * kRow + 4 + lane] * m);
-        index = static_cast<int>((static_cast<unsigned>(index) + static_cast<unsigned>(L) * static_cast<unsigned>(p.step)) & frac_mask);
-        wave_sync();
-        if (lane < 8) advance_row(I.lds + lane * kRow, L);
-        wave_sync();
-    }
-    __device__ void finish(const Inst& I)
-    {
-        oalsfx_ringmod_state& s = I.ss->u.ringmod;
-        if (I.lane < 4) store_hist(I.lds + I.lane * kRow, I.lds + (4 + I.lane) * kRow, s.hist[I.lane]);
-        if (I.lane == 0) s.index = index;
-    }
-};
-
-// echo (reference src/oalsfxpp.cpp:4887-4962): t1 = ring[o - tap1], t2 = ring[o - tap2]; in = t2 + x; ring[o] = biquad(in) * feed.
-// Row 0 the filter input, row 1 its output.  tap1 <= tap2, so sub-blocks of min(64, tap1) samples read settled data only.
-struct EchoW {
-    int offset;
-    float n_t1, n_t2;   // taps of the next tile, requested one tile ahead when both taps are at least two tiles long
-    bool have_next;
-    __device__ void init(const Inst& I)
-    {
-        offset = I.ss->u.echo.offset;
-        n_t1 = n_t2 = 0.0F;
-        have_next = false;
-        if (I.lane == 0) load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
-        wave_sync();
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.echo;
-        const int lane = I.lane;
-        const unsigned mask = static_cast<unsigned>(p.ring_len - 1);
-        const Coef c = coef(p.filter);
-        const int o = offset + lane;
-        const int block = max(1, min(64, min(p.tap1, p.tap2)));
-        float* xrow = I.lds;
-        float* yrow = I.lds + kRow;
-        float* wrow = I.lds + 2 * kRow; // what this tile writes to the ring; taps shorter than the tile read it here
-        // taps whose source lies before the tile: one round of ring loads
-        const bool in1 = p.tap1 > 0 && lane - p.tap1 >= 0, in2 = p.tap2 > 0 && lane - p.tap2 >= 0;
-        float t1 = 0.0F, t2 = 0.0F;
-        if (have_next) {
-            t1 = n_t1; t2 = n_t2;
-        } else if (lane < L) {
-            if (!in1) t1 = I.ring[static_cast<unsigned>(o - p.tap1) & mask];
-            if (!in2) t2 = I.ring[static_cast<unsigned>(o - p.tap2) & mask];
-        }
-        // the next tile's taps lie before this tile's writes when both are at least two tiles long: request them now
-        have_next = L == 64 && p.tap1 >= 128 && p.tap2 >= 128;
-        if (have_next) {
-            n_t1 = I.ring[static_cast<unsigned>(o + 64 - p.tap1) & mask];
-            n_t2 = I.ring[static_cast<unsigned>(o + 64 - p.tap2) & mask];
-        }
-        for (int s = 0; s < L; s += block) {
-            const int e = min(L, s + block);
-            const bool mine = lane >= s && lane < e;
-            if (mine) {
-                if (in1) t1 = wrow[4 + lane - p.tap1];
-                if (in2) t2 = wrow[4 + lane - p.tap2];
-                xrow[4 + lane] = t2 + wet[0];
-            }
-            wave_sync();
-            if (mine) {
-                const float* x = xrow + 4 + lane;
-                yrow[4 + lane] = ((x[0] * c.b0) + (x[-1] * c.b1)) + (x[-2] * c.b2);
-            }
-            wave_sync();
-            if (lane == 0) chain_biquad(yrow, s, e, c.a1, c.a2);
-            wave_sync();
-            if (mine) wrow[4 + lane] = yrow[4 + lane] * p.feed_gain;
-            wave_sync();
-        }
-        if (lane < L) I.ring[static_cast<unsigned>(o) & mask] = wrow[4 + lane];
-#pragma unroll
-        for (int ch = 0; ch < CH; ++ch) {
-            if (ch >= I.channels) continue;
-            const float g0 = p.gains[0][ch];
-            if (audible(g0)) out[ch] += t1 * g0;
-            const float g1 = p.gains[1][ch];
-            if (audible(g1)) out[ch] += t2 * g1;
-        }
-        offset += L;
-        wave_sync();
-        if (lane < 2) advance_row(I.lds + lane * kRow, L);
-        wave_sync();
-    }
-    __device__ void finish(const Inst& I)
-    {
-        if (I.lane == 0) {
-            store_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
-            I.ss->u.echo.offset = offset;
-        }
-    }
-};
-
-// distortion (reference src/oalsfxpp.cpp:4675-4750): 4x zero-stuffed oversampling, low-pass, three-stage wave shaper,
-// band-pass, keep every fourth sample.  Three arrays of 4 + 256 floats: low-pass sums/outputs, shaped samples,
-// band-pass sums/outputs; oversampled sample n of the tile belongs to frame n / 4.
-struct DistortionW {
-    static constexpr int kArr = 4 + 4 * 64;
-    float x_hist0, x_hist1; // low-pass input history (zeros after the first frame: the stuffed samples)
-    __device__ void init(const Inst& I)
-    {
-        const oalsfx_distortion_state& s = I.ss->u.distortion;
-        x_hist0 = s.low_pass.x[0];
-        x_hist1 = s.low_pass.x[1];
-        if (I.lane == 0) {
-            float* lp = I.lds; float* sh = I.lds + kArr; float* bp = I.lds + 2 * kArr;
-            lp[2] = s.low_pass.y[1]; lp[3] = s.low_pass.y[0];
-            sh[2] = s.band_pass.x[1]; sh[3] = s.band_pass.x[0];
-            bp[2] = s.band_pass.y[1]; bp[3] = s.band_pass.y[0];
-        }
-        wave_sync();
-    }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
-    {
-        const auto& p = I.sp->u.distortion;
-        const int lane = I.lane;
-        float* lp = I.lds; float* sh = I.lds + kArr; float* bp = I.lds + 2 * kArr;
-        const int n = 4 * L;
-        {
-            // low-pass feed-forward sums of this frame's four oversampled inputs (X, 0, 0, 0)
-            const Coef c = coef(p.low_pass);
-            const float X = wet[0] * 4.0F;
-            const float z = 0.0F;
-            const float p1 = lane == 0 ? x_hist0 : z; // input before this frame
-            const float p2 = lane == 0 ? x_hist1 : z;
-            float4 u;
-            u.x = ((c.b0 * X) + (c.b1 * p1)) + (c.b2 * p2);
-            u.y = ((c.b0 * z) + (c.b1 * X)) + (c.b2 * p1);
-            u.z = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * X);
-            u.w = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * z);
-            *reinterpret_cast<float4*>(lp + 4 + 4 * lane) = u;
-            wave_sync();
-            if (lane == 0) chain_biquad(lp, 0, n, c.a1, c.a2);
-            wave_sync();
-        }
-        const float fc = p.edge_coeff;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int k = m * 64 + lane;
-            float smp = lp[4 + k];
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp))) * -1.0F;
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
-            sh[4 + k] = smp;
-        }
-        wave_sync();
-        {
-            const Coef c = coef(p.band_pass);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int k = m * 64 + lane;
-                const float* x = sh + 4 + k;
-                bp[4 + k] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
-            }
-            wave_sync();
-            if (lane == 0) chain_biquad(bp, 0, n, c.a1, c.a2);
-            wave_sync();
-        }
-        const float kept = bp[4 + 4 * lane];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const float g = p.gains[c] * p.attenuation;
-            if (c < I.channels && audible(g)) out[c] += g * kept;
-        }
-        wave_sync();
-        if (lane < 3) advance_row(I.lds + lane * kArr, n);
-        if (L > 0) { x_hist0 = 0.0F; x_hist1 = 0.0F; }
-        wave_sync();
-    }
-    __device__ void finish(const Inst& I)
-    {
-        if (I.lane == 0) {
-            oalsfx_distortion_state& s = I.ss->u.distortion;
-            const float* lp = I.lds; const float* sh = I.lds + kArr; const float* bp = I.lds + 2 * kArr;
-            s.low_pass.x[0] = x_hist0; s.low_pass.x[1] = x_hist1;
-            s.low_pass.y[1] = lp[2]; s.low_pass.y[0] = lp[3];
-            s.band_pass.x[1] = sh[2]; s.band_pass.x[0] = sh[3];
-            s.band_pass.y[1] = bp[2]; s.band_pass.y[0] = bp[3];
-        }
-    }
-};
-
-static_assert(3 * DistortionW::kArr <= kLdsFloats, "distortion arrays must fit the per-wave LDS");
-
-// One instance on one wavefront: the front end (dry mix / B-format send of mix_source, reference
-// src/oalsfxpp.cpp:2917-2982), the effect body tile by tile, the back end (write_f32, :3414-3431).
-template <int CH, class Fx>
-__device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, int inst, int flags, float* lds, int lane)
-{
-    const int channels = (CH == 8) ? ctx.channels : CH;
-    const int frames = ctx.frames;
-    const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
-    // send gains through the constant address space: scalar loads, hoisted out of the tile loop
-    typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
-    ConstSourceParams& SRC = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
-    const bool first = (flags & kFirst) != 0;
-    const bool last = (flags & kLast) != 0;
-    const bool filtered = (flags & kFiltered) != 0 && instance_has_send_filter(ctx, inst);
-    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
-    const float* wsrc = src;
-    if (filtered) {
-        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
-        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
-    }
-    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
-    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * channels * OALSFX_MAX_CHUNK : nullptr;
-    const bool send_on = SRC.aux[slot].out_channels != 0;
-
-    Inst I;
-    I.sp = (ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
-    I.ss = ctx.state + sidx;
-    I.ring = (GlobalFloat*)(uintptr_t)ctx.rings[sidx];
-    I.lds = lds;
-    I.lane = lane;
-    I.channels = channels;
-
-    // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock around the parts of slot 0's tiles
-    int ts_i = 0;
-    auto stamp = [&]() {
-        if (ctx.timeline && slot == 0 && (inst & 63) == 0 && (inst >> 6) < 64 && lane == 0 && ts_i < 96)
-            ctx.timeline[64 * 4 * 96 + (inst >> 6) * 96 + ts_i++] = clock64();
-    };
-    stamp();
-    Fx fx;
-    fx.init(I);
-    stamp();
-
-    // the inputs of a tile (source frame, filtered send input, accumulated mix of the earlier slots) do not depend on the effect:
-    // they are requested one tile ahead, so that their latency hides behind the body of the current tile
-    float n_in[CH], n_win[CH], n_mix[CH];
-    auto request = [&](int base) {
-        const int p = base + lane;
-        const bool a = p < frames;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { n_in[c] = 0.0F; n_mix[c] = 0.0F; }
-        if (a) {
-            if (CH == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(p) * 2);
-                n_in[0] = v.x; n_in[CH - 1] = v.y;
-            } else {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < channels) n_in[c] = src[static_cast<size_t>(p) * channels + c];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < CH; ++c) n_win[c] = n_in[c];
-        if (filtered && a) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < channels) n_win[c] = wsrc[static_cast<size_t>(p) * channels + c];
-        }
-        if (!first && a) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < channels) n_mix[c] = mixbuf[c * OALSFX_MAX_CHUNK + p];
-        }
-    };
-    request(0);
-    for (int base = 0; base < frames; base += 64) {
-        const int L = min(64, frames - base);
-        const bool act = lane < L;
-        const int pos = base + lane;
-        float in[CH], win[CH], out[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) { in[c] = n_in[c]; win[c] = n_win[c]; out[c] = 0.0F; }
-        float mix[CH];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) mix[c] = n_mix[c];
-        if (base + 64 < frames) request(base + 64);
-        __builtin_amdgcn_sched_barrier(0); // keep the requests up here
-        float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (c >= channels) continue;
-            if (first) {
-#pragma unroll
-                for (int o = 0; o < CH; ++o) {
-                    const float g = SRC.direct.gains[c][o];
-                    if (o < channels && audible(g)) out[o] += in[c] * g;
-                }
-            }
-            if (send_on) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float g = SRC.aux[slot].gains[c][k];
-                    if (audible(g)) wet[k] += win[c] * g;
-                }
-            }
-        }
-        if (!first) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) out[c] = mix[c];
-        }
-        stamp();
-        fx.template tile<CH>(I, wet, out, L);
-        stamp();
-
-        if (act) {
-            if (last) {
-                if (CH == 2) {
-                    *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(out[0], out[CH - 1]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        if (c < channels) dst[static_cast<size_t>(pos) * channels + c] = out[c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < channels) mixbuf[c * OALSFX_MAX_CHUNK + pos] = out[c];
-            }
-        }
-    }
-
-    fx.finish(I);
-    if (lane == 0) I.ss->seen_seq = I.sp->update_seq;
-    if (first && !filtered && lane < channels) send_history_follow(ctx, inst, lane, channels, frames, src);
-}
-
-} // namespace
 
 // One wavefront per listed instance, any mix of the ring-light effect types, for `slot_count` consecutive slots starting at
 // `slot`: the host fuses runs of slots that hold no reverb at all, so that an instance's chorus -> flanger -> echo chain
@@ -676,35 +9,13 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
 template <int CH>
 __global__ __launch_bounds__(256) void k_wave_effects(KernelCtx ctx, int slot, int slot_count, const int* __restrict__ list, int count, int flags)
 {
-    __shared__ __attribute__((aligned(16))) float lds_all[4][kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float lds_all[4][wfx::kLdsFloats];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int w = blockIdx.x * 4 + wib;
     if (w >= count) return; // whole wavefronts leave; the kernel has no workgroup barrier
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
-    float* lds = lds_all[wib];
-    for (int sl = slot; sl < slot + slot_count; ++sl) {
-        const int f = (flags & kFiltered) | ((flags & kFirst) && sl == slot ? kFirst : 0) | ((flags & kLast) && sl == slot + slot_count - 1 ? kLast : 0);
-        const int type = __builtin_amdgcn_readfirstlane(ctx.params[static_cast<size_t>(inst) * ctx.slots + sl].type);
-        KernelCtx c = ctx;
-        c.wet_src = ctx.wet_src + static_cast<size_t>(sl - slot) * ctx.wet_plane;
-        switch (type) {
-        case OALSFX_NULL:
-            if (f & (kFirst | kLast)) wave_instance<CH, NullW>(c, sl, inst, f, lds, lane); // a null effect in the middle does nothing
-            break;
-        case OALSFX_CHORUS:
-        case OALSFX_FLANGER: wave_instance<CH, ModDelayW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_COMPRESSOR: wave_instance<CH, CompressorW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_DEDICATED_DIALOG:
-        case OALSFX_DEDICATED_LFE: wave_instance<CH, DedicatedW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_DISTORTION: wave_instance<CH, DistortionW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_ECHO: wave_instance<CH, EchoW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_EQUALIZER: wave_instance<CH, EqualizerW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_RING_MODULATOR: wave_instance<CH, RingModW>(c, sl, inst, f, lds, lane); break;
-        default: break;
-        }
-        wave_sync(); // the next slot of this instance reads the mix this one just wrote (same wavefront, program order)
-    }
+    wfx::wave_slots<CH>(ctx, slot, slot_count, inst, flags, lds_all[wib], lane);
 }
 
 void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, int flags, hipStream_t stream)
