@@ -161,9 +161,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
+    # one process per GPU: LOCAL_RANK picks the device; if the launcher narrowed the visible devices to one per process
+    # (HIP_VISIBLE_DEVICES), that one is device 0
+    visible = torch.cuda.device_count()
+    local_rank = local_rank % visible if visible > 0 else local_rank
     torch.cuda.set_device(local_rank)
+    # RCCL ("nccl") between the ranks; OALSFX_DIST_BACKEND=gloo is for rehearsing the N > 1 path where the ranks share a GPU
+    backend = os.environ.get("OALSFX_DIST_BACKEND", "nccl")
     if distributed:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     n = args.instances or (8192 if args.workload == "config4" else 4096)
     workload = "config2-presets" if args.preset_mix else args.workload
@@ -209,7 +218,7 @@ def main():
     elapsed = time.perf_counter() - t0
     sharding.barrier()
     torch.cuda.synchronize()
-    elapsed = sharding.max_over_ranks(elapsed, device="cuda")
+    elapsed = sharding.max_over_ranks(elapsed, device="cuda" if backend == "nccl" else "cpu")
 
     # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
     kernels = {}
