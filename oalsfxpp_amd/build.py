@@ -23,6 +23,12 @@ COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra",
 DEVICE = ["--offload-arch=gfx950", "-x", "hip"]  # fp32 denormals stay on (the gfx9 default): the reference computes with them
 
 
+# per-source additions
+EXTRA = {
+    "hip/wave_effects.hip": ["-fno-slp-vectorize"],
+}
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -51,7 +57,7 @@ def build_all(force=False, verbose=False):
         objs.append(obj)
         if not (force or _newer(src, obj, headers)):
             continue
-        cmd = [hipcc] + COMMON + (DEVICE if rel in HIP_SOURCES else []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + COMMON + (DEVICE if rel in HIP_SOURCES else []) + EXTRA.get(rel, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((rel, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

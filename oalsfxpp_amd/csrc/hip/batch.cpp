@@ -468,7 +468,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 int debug_flags()
 {
     // timing experiments only (OALSFX_DEBUG_FLAGS): 8 every reverb through the general kernel, 32 / 64 tap distances rounded
-    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two launches)
+    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two launches), 0x100000 no cooperative workgroups for the ring-light effects
     static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
     return v;
 }
@@ -537,17 +537,51 @@ void launch_reverb_general_part(oalsfx_batch* b, bool everything, const KernelCt
     oalsfx_hip::launch_reverb_general(ctx, slot, b->d_lists + offset, count, flags, stream);
 }
 
+// Effect types whose filter recurrences gain from cooperative workgroups (wave_effects_body.hpp, chain_phase).
+bool cooperative_type(int type)
+{
+    // (the compressor's follower goes through chain_phase too, but a wavefront's own is as fast: it is short, and what a
+    // workgroup saves in instructions it loses at the two barriers)
+    return type == OALSFX_DISTORTION || type == OALSFX_EQUALIZER || type == OALSFX_RING_MODULATOR;
+}
+
+// The ring-light types of a slot from `first_type` on as segments of one grid: per type the whole workgroups (cooperative
+// where the type gains from it), then the up to three instances left over.  Returns the number of instances covered.
+int wave_segments(const oalsfx_batch* b, int slot, int first_type, oalsfx_hip::WaveSegments& seg)
+{
+    seg = oalsfx_hip::WaveSegments{};
+    const bool coop_allowed = !(debug_flags() & 0x100000);
+    int total = 0;
+    auto add = [&](int count, bool coop) {
+        if (count <= 0) return;
+        seg.count[seg.n] = count;
+        if (coop) seg.coop_mask |= 1u << seg.n;
+        total += count;
+        seg.n += 1;
+    };
+    for (int t = first_type; t < OALSFX_REVERB; ++t) {
+        const int count = b->list_count[slot][t];
+        if (coop_allowed && cooperative_type(t) && count >= 4) {
+            add(count & ~3, true);
+            add(count & 3, false);
+        } else {
+            add(count, false);
+        }
+    }
+    return total;
+}
+
 // All ring-light effect types of a slot in one grid: their instance lists are adjacent in d_lists (types in
 // ascending order, the two reverb types last).
 void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
 {
     const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
     const int first_type = null_has_duty ? OALSFX_NULL : OALSFX_NULL + 1;
-    int count = 0;
-    for (int t = first_type; t < OALSFX_REVERB; ++t) count += b->list_count[slot][t];
+    oalsfx_hip::WaveSegments seg;
+    const int count = wave_segments(b, slot, first_type, seg);
     if (count == 0) return;
     ScopedTiming timing(b, kTimedWaveEffects, stream);
-    oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, flags, stream);
+    oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, &seg, flags, stream);
 }
 
 // Ring-light effects and believed-steady reverbs of one slot in one grid (k_slot_mixed).
@@ -555,14 +589,14 @@ void launch_mixed_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
 {
     const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
     const int first_type = null_has_duty ? OALSFX_NULL : OALSFX_NULL + 1;
-    int light = 0;
-    for (int t = first_type; t < OALSFX_REVERB; ++t) light += b->list_count[slot][t];
+    oalsfx_hip::WaveSegments seg;
+    const int light = wave_segments(b, slot, first_type, seg);
     const int steady = b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB];
     KernelCtx c = ctx;
     c.progress = nullptr; // an instance that turns out not to be steady falls back inside the grid
     ScopedTiming timing(b, kTimedMixed, stream);
     oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->list_offset[slot][OALSFX_REVERB], steady, b->d_lists + b->list_offset[slot][first_type], light,
-                                  flags, stream);
+                                  seg, flags, stream);
 }
 
 // Number of consecutive slots from `slot` on that hold no reverb at all: such a run is one fused launch over every instance.
@@ -627,7 +661,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                                       (filtered ? oalsfx_hip::kFiltered : 0);
                 {
                     ScopedTiming timing(b, kTimedWaveEffects, stream);
-                    oalsfx_hip::launch_wave_effects(ctx, s, run, b->d_lists + b->list_offset[s][OALSFX_NULL], b->n, run_flags, stream);
+                    oalsfx_hip::launch_wave_effects(ctx, s, run, b->d_lists + b->list_offset[s][OALSFX_NULL], b->n, nullptr, run_flags, stream);
                 }
                 s += run - 1;
                 continue;

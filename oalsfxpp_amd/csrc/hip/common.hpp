@@ -39,6 +39,23 @@ struct KernelCtx {
     unsigned long long* timeline;       // measurement only (OALSFX_DEBUG_TIMELINE): phase time stamps of sampled workgroups, else nullptr
 };
 
+// How the workgroups of a ring-light grid map to a slot's type-sorted instance list: segment k covers the next `count[k]` list
+// entries, four per workgroup (a segment starts a new workgroup).  A segment whose bit is set in coop_mask holds whole
+// workgroups of one effect type, which run their filter recurrences together (wave_effects_body.hpp, chain_phase).
+// n == 0: no segments, wavefront w takes list entry w.
+struct WaveSegments {
+    enum { kMax = 20 }; // ten ring-light types, each at most a cooperative part and a remainder
+    int n;
+    unsigned coop_mask;
+    int count[kMax];
+    __host__ __device__ int blocks() const
+    {
+        int b = 0;
+        for (int k = 0; k < n; ++k) b += (count[k] + 3) >> 2;
+        return b;
+    }
+};
+
 // Flags of one launch: which duties of the mix loop this slot's kernel performs.
 enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
@@ -59,10 +76,12 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
                           hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
-void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, int flags, hipStream_t stream);
+// `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments
+void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, const WaveSegments* seg, int flags,
+                         hipStream_t stream);
 // mono / stereo, whole tiles: the believed-steady reverbs and the ring-light effects of one slot in one grid (reverb.hip)
-void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count, int flags,
-                       hipStream_t stream);
+void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
+                       const WaveSegments& seg, int flags, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,

@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
 // concurrently, but ordering them against the caller's stream costs ~7 us at the fork and ~20 us at the join on this stack.
 template <int CH>
 __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, const int* __restrict__ steady_list, int steady_count,
-                                                       const int* __restrict__ light_list, int light_count, int flags)
+                                                       const int* __restrict__ light_list, int light_count, WaveSegments seg, int flags)
 {
     union Shared {
         SteadyShared<CH, 4> steady;
@@ -1509,20 +1509,17 @@ __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, 
         reverb_steady_group<CH, 4, false, true, true, true>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
         return;
     }
-    const int wib = threadIdx.x >> 6;
-    const int w = (group - steady_groups) * 4 + wib;
-    if (w >= light_count) return; // whole wavefronts leave; this half has no workgroup barrier
-    const int inst = __builtin_amdgcn_readfirstlane(light_list[w]);
-    wfx::wave_slots<CH>(ctx, slot, 1, inst, flags, sh.light[wib], threadIdx.x & 63);
+    wfx::wave_block<CH>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
 }
 
-void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count, int flags,
-                       hipStream_t stream)
+void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
+                       const WaveSegments& seg, int flags, hipStream_t stream)
 {
     if (ctx.frames <= 0 || steady_count + light_count <= 0) return;
-    const dim3 grid((steady_count + 3) / 4 + (light_count + 3) / 4), block(256);
-    if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, flags);
-    else OALSFX_LAUNCH((k_slot_mixed<2>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, flags);
+    const int light_blocks = seg.n > 0 ? seg.blocks() : (light_count + 3) / 4;
+    const dim3 grid((steady_count + 3) / 4 + light_blocks), block(256);
+    if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+    else OALSFX_LAUNCH((k_slot_mixed<2>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
 }
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to

@@ -48,22 +48,26 @@ __device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a
 {
     float y1 = row[4 + lo - 1], y2 = row[4 + lo - 2];
     int i = lo;
-    if ((lo & 3) == 0 && lo + 4 <= hi) {
-        // the next four sums are requested before the current four are worked on: the LDS latency hides behind the
-        // dependent arithmetic instead of adding to it
-        float4 u = *reinterpret_cast<const float4*>(row + 4 + lo);
-        for (; i + 4 <= hi; i += 4) {
-            float4 un = u;
-            if (i + 8 <= hi) un = *reinterpret_cast<const float4*>(row + 8 + i);
-            float4 y;
-            y.x = (u.x - (a1 * y1)) - (a2 * y2);
-            y.y = (u.y - (a1 * y.x)) - (a2 * y1);
-            y.z = (u.z - (a1 * y.y)) - (a2 * y.x);
-            y.w = (u.w - (a1 * y.z)) - (a2 * y.y);
-            *reinterpret_cast<float4*>(row + 4 + i) = y;
-            y2 = y.z;
-            y1 = y.w;
-            u = un;
+    auto step4 = [&](float4& v) {
+        v.x = (v.x - (a1 * y1)) - (a2 * y2);
+        v.y = (v.y - (a1 * v.x)) - (a2 * y1);
+        v.z = (v.z - (a1 * v.y)) - (a2 * v.x);
+        v.w = (v.w - (a1 * v.z)) - (a2 * v.y);
+        y2 = v.z;
+        y1 = v.w;
+    };
+    if ((lo & 3) == 0 && lo + 16 <= hi) {
+        // Sixteen samples at a time, entirely in registers, the next sixteen requested before the current ones are worked on:
+        // the recurrence then runs at the pace of its three dependent instructions per sample, with no LDS latency in it.
+        float4* r4 = reinterpret_cast<float4*>(row + 4);
+        float4 c0 = r4[(lo >> 2) + 0], c1 = r4[(lo >> 2) + 1], c2 = r4[(lo >> 2) + 2], c3 = r4[(lo >> 2) + 3];
+        for (; i + 16 <= hi; i += 16) {
+            const int q = i >> 2;
+            float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (i + 32 <= hi) { n0 = r4[q + 4]; n1 = r4[q + 5]; n2 = r4[q + 6]; n3 = r4[q + 7]; }
+            step4(c0); step4(c1); step4(c2); step4(c3);
+            r4[q + 0] = c0; r4[q + 1] = c1; r4[q + 2] = c2; r4[q + 3] = c3;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
     }
     for (; i < hi; ++i) {
@@ -105,7 +109,42 @@ struct Inst {
     float* lds;
     int lane;
     int channels;
+    // cooperative workgroups (four instances of one effect type, see chain_phase)
+    bool coop;
+    int wib;            // this wavefront's place in its workgroup
+    int duty;           // the wavefront that runs the workgroup's first chain phase; the duty moves on by one with every phase, so
+                        // that the chains of the workgroups that share a CU spread over its four SIMDs whatever their placement
+    mutable int phase;  // chain phases so far
+    float* group_lds;   // LDS of the workgroup's first wavefront
+    int group_stride;   // floats between the LDS areas of consecutive wavefronts
 };
+
+// Workgroup barrier that only waits for LDS traffic: global requests (the next tile's inputs) stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The serial part of a tile: `lines` recurrences per instance, f(lds of the instance, line) runs one of them over rows that
+// the parallel part has filled.  A lone wavefront runs its own on its first lanes.  In a cooperative workgroup (four
+// wavefronts = four instances of the same effect type, all present) one wavefront runs all 4 * lines on as many lanes while
+// the other three wait: a vector instruction costs the same four cycles whether it has one lane or sixteen, and these
+// recurrences are most of the instructions of the equalizer, the distortion and the compressor.  Coefficients the
+// recurrences need are kept in the rows' unused prefix slots ([0], [1]) so that any wavefront finds them.
+template <class F>
+__device__ __forceinline__ void chain_phase(const Inst& I, int lines, F&& f)
+{
+    if (!I.coop) {
+        wave_sync();
+        if (I.lane < lines) f(I.lds, I.lane);
+        wave_sync();
+    } else {
+        const int duty = (I.duty + I.phase++) & 3;
+        lds_barrier();
+        if (I.wib == duty && I.lane < 4 * lines) f(I.group_lds + (I.lane / lines) * I.group_stride, I.lane % lines);
+        lds_barrier();
+    }
+}
 
 // std::max / std::min as the reference uses them (first argument wins when the comparison is false, NaNs included)
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
@@ -213,7 +252,11 @@ struct ModDelayW {
 struct CompressorW {
     __device__ void init(const Inst& I)
     {
-        if (I.lane == 0) I.lds[3] = I.ss->u.compressor.gain_control;
+        if (I.lane == 0) {
+            I.lds[3] = I.ss->u.compressor.gain_control;
+            I.lds[0] = I.sp->u.compressor.attack_rate;
+            I.lds[1] = I.sp->u.compressor.release_rate;
+        }
         wave_sync();
     }
     template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
@@ -226,11 +269,10 @@ struct CompressorW {
             amplitude = std_max(amplitude + fabsf(wet[1]), std_max(amplitude + fabsf(wet[2]), amplitude + fabsf(wet[3])));
         }
         row[4 + I.lane] = amplitude;
-        wave_sync();
-        if (I.lane == 0) {
+        chain_phase(I, 1, [L](float* row, int) {
             // the gain follower is a serial min/max recurrence (reference :4385-4400)
             float gc = row[3];
-            const float attack = p.attack_rate, release = p.release_rate;
+            const float attack = row[0], release = row[1];
             auto follow = [&](float a) {
                 if (a > gc) gc = std_min(gc + attack, a);
                 else if (a < gc) gc = std_max(gc - release, a);
@@ -250,8 +292,7 @@ struct CompressorW {
             }
             for (; i < L; ++i) row[4 + i] = follow(row[4 + i]);
             row[3] = gc;
-        }
-        wave_sync();
+        });
         const float output = 1.0F / std_min(2.0F, std_max(0.5F, row[4 + I.lane])); // Math::clamp(gc, 0.5, 2) = min(max_value, max(min_value, gc))
         wave_sync();
 #pragma unroll
@@ -272,6 +313,9 @@ struct EqualizerW {
         if (I.lane < 16) {
             const int b = I.lane >> 2, ch = I.lane & 3;
             load_hist(I.lds + (b * 4 + ch) * kRow, I.lds + ((b + 1) * 4 + ch) * kRow, s.hist[b][ch]);
+            float* yrow = I.lds + ((b + 1) * 4 + ch) * kRow; // the band's feedback coefficients travel with its output rows
+            yrow[0] = I.sp->u.equalizer.band[b].a1;
+            yrow[1] = I.sp->u.equalizer.band[b].a2;
         }
         wave_sync();
     }
@@ -290,9 +334,10 @@ struct EqualizerW {
                 const float* x = I.lds + (b * 4 + ch) * kRow + 4 + lane;
                 I.lds[((b + 1) * 4 + ch) * kRow + 4 + lane] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
             }
-            wave_sync();
-            if (lane < 4) chain_biquad(I.lds + ((b + 1) * 4 + lane) * kRow, 0, L, c.a1, c.a2);
-            wave_sync();
+            chain_phase(I, 4, [b, L](float* lds, int line) {
+                float* row = lds + ((b + 1) * 4 + line) * kRow;
+                chain_biquad(row, 0, L, row[0], row[1]);
+            });
         }
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) pan<CH>(out, I.channels, p.gains[ch], I.lds[(16 + ch) * kRow + 4 + lane]);
@@ -318,7 +363,12 @@ struct RingModW {
     {
         const oalsfx_ringmod_state& s = I.ss->u.ringmod;
         index = s.index;
-        if (I.lane < 4) load_hist(I.lds + I.lane * kRow, I.lds + (4 + I.lane) * kRow, s.hist[I.lane]);
+        if (I.lane < 4) {
+            load_hist(I.lds + I.lane * kRow, I.lds + (4 + I.lane) * kRow, s.hist[I.lane]);
+            float* yrow = I.lds + (4 + I.lane) * kRow;
+            yrow[0] = I.sp->u.ringmod.filter.a1;
+            yrow[1] = I.sp->u.ringmod.filter.a2;
+        }
         wave_sync();
     }
     __device__ static float carrier(int waveform, int idx)
@@ -342,9 +392,10 @@ struct RingModW {
             const float* x = I.lds + ch * kRow + 4 + lane;
             I.lds[(4 + ch) * kRow + 4 + lane] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
         }
-        wave_sync();
-        if (lane < 4) chain_biquad(I.lds + (4 + lane) * kRow, 0, L, c.a1, c.a2);
-        wave_sync();
+        chain_phase(I, 4, [L](float* lds, int line) {
+            float* row = lds + (4 + line) * kRow;
+            chain_biquad(row, 0, L, row[0], row[1]);
+        });
         // the carrier index is pre-incremented: sample i sees index + (i + 1) * step (reference :5748-5752)
         const unsigned frac_mask = (1u << 24) - 1u;
         const int idx = static_cast<int>((static_cast<unsigned>(index) + static_cast<unsigned>(lane + 1) * static_cast<unsigned>(p.step)) & frac_mask);
@@ -462,6 +513,8 @@ struct DistortionW {
             lp[2] = s.low_pass.y[1]; lp[3] = s.low_pass.y[0];
             sh[2] = s.band_pass.x[1]; sh[3] = s.band_pass.x[0];
             bp[2] = s.band_pass.y[1]; bp[3] = s.band_pass.y[0];
+            lp[0] = I.sp->u.distortion.low_pass.a1; lp[1] = I.sp->u.distortion.low_pass.a2;
+            bp[0] = I.sp->u.distortion.band_pass.a1; bp[1] = I.sp->u.distortion.band_pass.a2;
         }
         wave_sync();
     }
@@ -484,9 +537,7 @@ struct DistortionW {
             u.z = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * X);
             u.w = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * z);
             *reinterpret_cast<float4*>(lp + 4 + 4 * lane) = u;
-            wave_sync();
-            if (lane == 0) chain_biquad(lp, 0, n, c.a1, c.a2);
-            wave_sync();
+            chain_phase(I, 1, [n](float* lds, int) { chain_biquad(lds, 0, n, lds[0], lds[1]); });
         }
         const float fc = p.edge_coeff;
 #pragma unroll
@@ -507,9 +558,10 @@ struct DistortionW {
                 const float* x = sh + 4 + k;
                 bp[4 + k] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
             }
-            wave_sync();
-            if (lane == 0) chain_biquad(bp, 0, n, c.a1, c.a2);
-            wave_sync();
+            chain_phase(I, 1, [n](float* lds, int) {
+                float* row = lds + 2 * kArr;
+                chain_biquad(row, 0, n, row[0], row[1]);
+            });
         }
         const float kept = bp[4 + 4 * lane];
 #pragma unroll
@@ -539,8 +591,17 @@ static_assert(3 * DistortionW::kArr <= kLdsFloats, "distortion arrays must fit t
 
 // One instance on one wavefront: the front end (dry mix / B-format send of mix_source, reference
 // src/oalsfxpp.cpp:2917-2982), the effect body tile by tile, the back end (write_f32, :3414-3431).
+// How a wavefront's workgroup is made up: `coop` says its four wavefronts hold four instances of one effect type and run
+// their recurrences together (chain_phase).
+struct Group {
+    bool coop;
+    int wib, duty;
+    float* lds;  // of the workgroup's first wavefront
+    int stride;  // floats between the wavefronts' LDS areas
+};
+
 template <int CH, class Fx>
-__device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, int inst, int flags, float* lds, int lane)
+__device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, int inst, int flags, float* lds, int lane, const Group& group)
 {
     const int channels = (CH == 8) ? ctx.channels : CH;
     const int frames = ctx.frames;
@@ -568,6 +629,12 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     I.lds = lds;
     I.lane = lane;
     I.channels = channels;
+    I.coop = group.coop;
+    I.wib = group.wib;
+    I.duty = group.duty;
+    I.phase = 0;
+    I.group_lds = group.lds;
+    I.group_stride = group.stride;
 
     // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock around the parts of slot 0's tiles
     int ts_i = 0;
@@ -675,9 +742,9 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
 
 
 // The slots `slot` .. `slot + slot_count - 1` of one instance on one wavefront, in order (`lds`: kLdsFloats floats of this
-// wavefront's own).
+// wavefront's own).  group.coop requires slot_count == 1 and the same effect type in all four wavefronts of the workgroup.
 template <int CH>
-__device__ __forceinline__ void wave_slots(const KernelCtx& ctx, int slot, int slot_count, int inst, int flags, float* lds, int lane)
+__device__ __forceinline__ void wave_slots(const KernelCtx& ctx, int slot, int slot_count, int inst, int flags, float* lds, int lane, const Group& group)
 {
     for (int sl = slot; sl < slot + slot_count; ++sl) {
         const int f = (flags & kFiltered) | ((flags & kFirst) && sl == slot ? kFirst : 0) | ((flags & kLast) && sl == slot + slot_count - 1 ? kLast : 0);
@@ -686,21 +753,51 @@ __device__ __forceinline__ void wave_slots(const KernelCtx& ctx, int slot, int s
         c.wet_src = ctx.wet_src + static_cast<size_t>(sl - slot) * ctx.wet_plane;
         switch (type) {
         case OALSFX_NULL:
-            if (f & (kFirst | kLast)) wave_instance<CH, NullW>(c, sl, inst, f, lds, lane); // a null effect in the middle does nothing
+            if (f & (kFirst | kLast)) wave_instance<CH, NullW>(c, sl, inst, f, lds, lane, group); // a null effect in the middle does nothing
             break;
         case OALSFX_CHORUS:
-        case OALSFX_FLANGER: wave_instance<CH, ModDelayW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_COMPRESSOR: wave_instance<CH, CompressorW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_FLANGER: wave_instance<CH, ModDelayW>(c, sl, inst, f, lds, lane, group); break;
+        case OALSFX_COMPRESSOR: wave_instance<CH, CompressorW>(c, sl, inst, f, lds, lane, group); break;
         case OALSFX_DEDICATED_DIALOG:
-        case OALSFX_DEDICATED_LFE: wave_instance<CH, DedicatedW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_DISTORTION: wave_instance<CH, DistortionW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_ECHO: wave_instance<CH, EchoW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_EQUALIZER: wave_instance<CH, EqualizerW>(c, sl, inst, f, lds, lane); break;
-        case OALSFX_RING_MODULATOR: wave_instance<CH, RingModW>(c, sl, inst, f, lds, lane); break;
+        case OALSFX_DEDICATED_LFE: wave_instance<CH, DedicatedW>(c, sl, inst, f, lds, lane, group); break;
+        case OALSFX_DISTORTION: wave_instance<CH, DistortionW>(c, sl, inst, f, lds, lane, group); break;
+        case OALSFX_ECHO: wave_instance<CH, EchoW>(c, sl, inst, f, lds, lane, group); break;
+        case OALSFX_EQUALIZER: wave_instance<CH, EqualizerW>(c, sl, inst, f, lds, lane, group); break;
+        case OALSFX_RING_MODULATOR: wave_instance<CH, RingModW>(c, sl, inst, f, lds, lane, group); break;
         default: break;
         }
         wave_sync(); // the next slot of this instance reads the mix this one just wrote (same wavefront, program order)
     }
+}
+
+// The ring-light part of a grid: workgroup `block` of it, four wavefronts.  With segments (a single slot), the blocks follow
+// the slot's type-sorted list segment by segment, so that a workgroup holds one effect type; without, wavefront w takes
+// list[w].
+template <int CH>
+__device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int slot_count, const int* __restrict__ list, int count,
+                                           const WaveSegments& seg, int flags, int block, float* lds_group, int lds_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Group group{false, wib, block & 3, lds_group, lds_stride};
+    int w = block * 4 + wib;
+    if (seg.n > 0) {
+        int k = 0, first_block = 0, offset = 0;
+        for (; k + 1 < seg.n; ++k) {
+            const int b = (seg.count[k] + 3) >> 2;
+            if (block < first_block + b) break;
+            first_block += b;
+            offset += seg.count[k];
+        }
+        const int local = (block - first_block) * 4 + wib;
+        group.coop = ((seg.coop_mask >> k) & 1u) != 0;
+        if (local >= seg.count[k]) return; // never in a cooperative segment: those hold whole workgroups only
+        w = offset + local;
+    } else if (w >= count) {
+        return; // whole wavefronts leave; no workgroup barrier on this path
+    }
+    const int inst = __builtin_amdgcn_readfirstlane(list[w]);
+    wave_slots<CH>(ctx, slot, slot_count, inst, flags, lds_group + wib * lds_stride, lane, group);
 }
 
 } // namespace wfx
