@@ -25,7 +25,8 @@ namespace wfx {
 
 constexpr int kRow = 68;
 constexpr int kLdsRows = 20;                  // equalizer: 5 stages x 4 B-format channels
-constexpr int kLdsFloats = kLdsRows * kRow;   // distortion needs 3 x (4 + 256)
+constexpr int kCoefBase = kLdsRows * kRow;    // behind the rows: 4 x 8 floats, the equalizer's band coefficients
+constexpr int kLdsFloats = kCoefBase + 32;    // distortion needs 3 x (4 + 256)
 
 typedef __attribute__((address_space(1))) float GlobalFloat;
 // Parameters are read through the constant address space: scalar loads, hoisted out of the tile loop.
@@ -305,19 +306,52 @@ struct CompressorW {
 };
 
 // equalizer (reference src/oalsfxpp.cpp:5161-5213): four cascaded biquads on each B-format channel.
-// Row (stage * 4 + channel): stage 0 the input, stage b + 1 the output of band b.
+// Row (stage * 4 + channel): stage 0 the input, stage b + 1 the output of band b; a row's prefix holds the two samples
+// before the tile, which are both the band's output history and the next band's input history.
+// The sixteen filters of an instance run as a pipeline on sixteen lanes: lane (band b, channel c) filters 16-sample block
+// r - b in round r, one block behind the band that feeds it, so a tile takes 4 + 3 rounds of 16 serial steps instead of
+// 4 x 64.  Each lane computes its filter whole (feed-forward sums and recurrence, (b0 x0 + b1 x1) + b2 x2 then
+// (u - a1 y1) - a2 y2 as FilterState::process rounds them).
 struct EqualizerW {
+    static constexpr int kBlock = 16;
     __device__ void init(const Inst& I)
     {
         const oalsfx_equalizer_state& s = I.ss->u.equalizer;
         if (I.lane < 16) {
             const int b = I.lane >> 2, ch = I.lane & 3;
             load_hist(I.lds + (b * 4 + ch) * kRow, I.lds + ((b + 1) * 4 + ch) * kRow, s.hist[b][ch]);
-            float* yrow = I.lds + ((b + 1) * 4 + ch) * kRow; // the band's feedback coefficients travel with its output rows
-            yrow[0] = I.sp->u.equalizer.band[b].a1;
-            yrow[1] = I.sp->u.equalizer.band[b].a2;
+        }
+        if (I.lane < 4) {
+            const auto& band = I.sp->u.equalizer.band[I.lane];
+            float* cf = I.lds + kCoefBase + 8 * I.lane; // where any wavefront of a cooperative workgroup finds them
+            cf[0] = band.b0; cf[1] = band.b1; cf[2] = band.b2; cf[3] = band.a1; cf[4] = band.a2;
         }
         wave_sync();
+    }
+    // one lane, one filter, samples [n0, n1) of its rows
+    __device__ static void filter_block(const float* xrow, float* yrow, int n0, int n1, const float* cf)
+    {
+        const float b0 = cf[0], b1 = cf[1], b2 = cf[2], a1 = cf[3], a2 = cf[4];
+        float x1 = xrow[4 + n0 - 1], x2 = xrow[4 + n0 - 2], y1 = yrow[4 + n0 - 1], y2 = yrow[4 + n0 - 2];
+        auto step = [&](float x0) {
+            const float u = ((b0 * x0) + (b1 * x1)) + (b2 * x2);
+            const float y = (u - (a1 * y1)) - (a2 * y2);
+            x2 = x1; x1 = x0; y2 = y1; y1 = y;
+            return y;
+        };
+        if (n1 - n0 == kBlock) {
+            const float4* x4 = reinterpret_cast<const float4*>(xrow + 4 + n0);
+            float4* y4 = reinterpret_cast<float4*>(yrow + 4 + n0);
+            float4 v[4] = {x4[0], x4[1], x4[2], x4[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k].x = step(v[k].x); v[k].y = step(v[k].y); v[k].z = step(v[k].z); v[k].w = step(v[k].w);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y4[k] = v[k];
+        } else {
+            for (int n = n0; n < n1; ++n) yrow[4 + n] = step(xrow[4 + n]);
+        }
     }
     template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
     {
@@ -325,20 +359,18 @@ struct EqualizerW {
         const int lane = I.lane;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) I.lds[ch * kRow + 4 + lane] = wet[ch];
-        wave_sync();
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const Coef c = coef(p.band[b]);
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                const float* x = I.lds + (b * 4 + ch) * kRow + 4 + lane;
-                I.lds[((b + 1) * 4 + ch) * kRow + 4 + lane] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
+        chain_phase(I, 16, [L](float* lds, int line) {
+            const int b = line >> 2, ch = line & 3;
+            const float* xrow = lds + (b * 4 + ch) * kRow;
+            float* yrow = lds + ((b + 1) * 4 + ch) * kRow;
+            const float* cf = lds + kCoefBase + 8 * b;
+            const int blocks = (L + kBlock - 1) / kBlock;
+            for (int r = 0; r < blocks + 3; ++r) {
+                const int k = r - b;
+                if (k >= 0 && k < blocks) filter_block(xrow, yrow, k * kBlock, min(L, (k + 1) * kBlock), cf);
+                wave_sync(); // the band behind reads this block in the next round
             }
-            chain_phase(I, 4, [b, L](float* lds, int line) {
-                float* row = lds + ((b + 1) * 4 + line) * kRow;
-                chain_biquad(row, 0, L, row[0], row[1]);
-            });
-        }
+        });
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) pan<CH>(out, I.channels, p.gains[ch], I.lds[(16 + ch) * kRow + 4 + lane]);
         wave_sync();
