@@ -5,70 +5,256 @@
 namespace oalsfx_hip {
 
 // Send shelf filters as a pre-pass (reference apply_filters, src/oalsfxpp.cpp:3101-3143, called from mix_source :2929-2965).
-// One lane per (instance, send, input channel): it runs that send's two biquads over the chunk in sample order, so the
-// recurrences round like the reference's; a wavefront packs as many instances as fit its 64 lanes (16 for a stereo batch
-// with one slot).  Only instances with a filter switched on are handled (their sends without one copy their input, which
-// lets the effect kernels read every send of such an instance from the same place).  Runs only while some instance of the
-// batch has a filter switched on.
+// A wavefront takes two consecutive instances (one where its lanes or LDS rows do not reach: a recurrence per send and input
+// channel); the instances without a filter switched on are skipped -- the effect kernels read the raw input for them and keep
+// their histories -- and a wavefront without any leaves at once.  Per 64-frame tile, with LDS rows [instance][input channel]
+// and [instance][send][channel]:
+//   1. lane = frame: the frames of every instance go into the input rows (requested one tile ahead);
+//   2. lane = frame: per send, the feed-forward sums of the first shelf (or the input itself where that shelf is off);
+//   3. lane = (instance, send, channel): the recurrence of the first shelf, in 16-sample register blocks;
+//   4. lane = frame: the feed-forward sums of the second shelf, 5. its recurrence; 6. lane = frame: one plane per send out.
+// A stage that is switched off passes its input through and lets its history follow it, as process_pass_through does
+// (:1038-1056).  The histories stay in the recurrence lanes' registers from the first tile to the last.  A send to a null
+// slot is disabled: no plane written, histories frozen (:2952-2956).
+// (Tried before: whole filters, feed-forward sums included, in the recurrence lanes -- 24 instructions per
+// sample on the serial path instead of 8.)
+namespace {
+constexpr int kFilterRow = 4 + 64; // [2], [3]: the two samples before the tile; data from [4], 16-byte aligned
+constexpr int kFilterRowsPerWave = 48;
+constexpr int kFilterInstances = 2; // per wavefront, see filter_instances_per_wave
+constexpr int kFilterTable = kFilterInstances * 5 * 8; // per (instance, send): b0 b1 b2 of either shelf, which shelves are on, enabled
+
+// instances per wavefront: two where they have lanes and LDS rows.  (Measured on the headline batch with a shelf on every
+// direct send, step time against 59 us without filters: 1 instance per wavefront 90 us, 2: 78, 4: 86, 8: 106 -- the
+// recurrences cost a wavefront the same for one lane or sixty-four, the lane = frame phases grow with the instances.)
+inline __host__ __device__ int filter_instances_per_wave(int channels, int slots)
+{
+    const int chains = (1 + slots) * channels, rows = channels + chains;
+    int n = 64 / chains;
+    if (n > kFilterRowsPerWave / rows) n = kFilterRowsPerWave / rows;
+    return n < 1 ? 1 : (n > kFilterInstances ? kFilterInstances : n);
+}
+
+// y = (u - a1 y1) - a2 y2 over n entries of a row that holds the feed-forward sums; outputs replace them
+__device__ __forceinline__ void filter_recurrence(float* row, int n, float a1, float a2, float& y1, float& y2)
+{
+    auto step4 = [&](float4& v) {
+        v.x = (v.x - (a1 * y1)) - (a2 * y2);
+        v.y = (v.y - (a1 * v.x)) - (a2 * y1);
+        v.z = (v.z - (a1 * v.y)) - (a2 * v.x);
+        v.w = (v.w - (a1 * v.z)) - (a2 * v.y);
+        y2 = v.z;
+        y1 = v.w;
+    };
+    int i = 0;
+    if (n == 64) {
+        float4* r4 = reinterpret_cast<float4*>(row + 4);
+        float4 c0 = r4[0], c1 = r4[1], c2 = r4[2], c3 = r4[3];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (q + 4 < 16) { n0 = r4[q + 4]; n1 = r4[q + 5]; n2 = r4[q + 6]; n3 = r4[q + 7]; }
+            step4(c0); step4(c1); step4(c2); step4(c3);
+            r4[q] = c0; r4[q + 1] = c1; r4[q + 2] = c2; r4[q + 3] = c3;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        i = 64;
+    }
+    for (; i < n; ++i) {
+        const float y = (row[4 + i] - (a1 * y1)) - (a2 * y2);
+        row[4 + i] = y;
+        y2 = y1;
+        y1 = y;
+    }
+}
+}
+
 __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float* __restrict__ src_all, long long src_stride,
                                                       float* __restrict__ filtered, size_t send_floats, int instances)
 {
+    __shared__ __attribute__((aligned(16))) float filter_lds[4][kFilterRowsPerWave * kFilterRow + kFilterTable];
     const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
     const int channels = ctx.channels;
-    const int lanes_per_instance = (1 + ctx.slots) * channels;   // <= 5 * 8
-    const int instances_per_wave = 64 / lanes_per_instance;
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int sub = lane / lanes_per_instance, r = lane % lanes_per_instance;
-    const int inst = wave * instances_per_wave + sub;
-    if (sub >= instances_per_wave || inst >= instances) return;
-    if (!instance_has_send_filter(ctx, inst)) return; // the effect kernels read the raw input for this instance and keep its histories
-    const int send = r / channels;
-    const int c = r % channels;
-    const oalsfx_source_params& P = ctx.source[inst];
-    const oalsfx_send_params& sp = send == 0 ? P.direct : P.aux[send - 1];
-    if (send > 0 && sp.out_channels == 0) return; // null slot: the send is disabled and its history frozen
-    oalsfx_source_state& S = ctx.source_state[inst];
-    oalsfx_hist_t lp = S.lp[send][c];
-    oalsfx_hist_t hp = S.hp[send][c];
+    const int sends = 1 + ctx.slots;
+    const int chains = sends * channels; // <= 5 * 8
+    const int rows = channels + chains;  // LDS rows of one instance: its input channels, then one row per recurrence
+    const int ipw = filter_instances_per_wave(channels, ctx.slots);
+    const int first = (blockIdx.x * 4 + wib) * ipw;
+    if (first >= instances) return; // whole wavefronts leave; no workgroup barrier in this kernel
+    // which of this wavefront's instances have a filter switched on
+    const unsigned long long todo_mask = __ballot(lane < ipw && first + lane < instances && instance_has_send_filter(ctx, first + lane));
+    if (todo_mask == 0ULL) return;
+    float* lds = filter_lds[wib];
+    float* table = lds + kFilterRowsPerWave * kFilterRow;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // ---- recurrence lanes: (instance of the wavefront, send, input channel) ----
+    const int sub = lane / chains, r = lane % chains;
+    const int send = r / channels, c = r % channels;
+    const bool chain_lane = sub < ipw && ((todo_mask >> sub) & 1ULL) != 0;
+    const int my_inst = chain_lane ? first + sub : first;
+    const oalsfx_source_params& P = ctx.source[my_inst];
+    oalsfx_source_state& S = ctx.source_state[my_inst];
+    const oalsfx_send_params* spp = &P.direct;
+    if (chain_lane && send > 0) spp = &P.aux[send - 1];
+    const oalsfx_send_params& sp = *spp;
+    const bool enabled = chain_lane && (send == 0 || sp.out_channels != 0);
+    const bool lp_on = (sp.filter_type & OALSFX_AF_LOW_PASS) != 0, hp_on = (sp.filter_type & OALSFX_AF_HIGH_PASS) != 0;
     const oalsfx_biquad_t clp = sp.lp, chp = sp.hp;
-    const int type = sp.filter_type;
-    const float* src = src_all + static_cast<size_t>(inst) * src_stride + c;
-    float* out = filtered + static_cast<size_t>(send) * send_floats + static_cast<size_t>(inst) * ctx.src_stride + c;
-    const int frames = ctx.frames;
-    // eight frames at a time, the next eight requested before the current eight are filtered: the recurrence never waits for
-    // the strided input
-    float nx[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) nx[k] = (k < frames) ? src[static_cast<size_t>(k) * channels] : 0.0F;
-    for (int base = 0; base < frames; base += 8) {
-        float x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = nx[k];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) nx[k] = (base + 8 + k < frames) ? src[static_cast<size_t>(base + 8 + k) * channels] : 0.0F;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (base + k >= frames) break;
-            float y = x[k];
-            if (type & OALSFX_AF_LOW_PASS) y = biquad_step(clp, lp, y);
-            else { lp.x[1] = lp.x[0]; lp.x[0] = y; lp.y[1] = lp.y[0]; lp.y[0] = y; }
-            if (type & OALSFX_AF_HIGH_PASS) {
-                // with only the second filter on, it sees the raw input and the first follows the raw input too
-                y = biquad_step(chp, hp, y);
-            } else { hp.x[1] = hp.x[0]; hp.x[0] = y; hp.y[1] = hp.y[0]; hp.y[0] = y; }
-            out[static_cast<size_t>(base + k) * channels] = y;
-        }
+    // x: input, y: output of the first shelf = input of the second (the reference keeps that history twice; the copies are
+    // equal after every call), z: output of the second shelf
+    float x1 = 0.0F, x2 = 0.0F, y1 = 0.0F, y2 = 0.0F, z1 = 0.0F, z2 = 0.0F;
+    if (enabled) {
+        const oalsfx_hist_t lp = S.lp[send][c], hp = S.hp[send][c];
+        x1 = lp.x[0]; x2 = lp.x[1]; y1 = lp.y[0]; y2 = lp.y[1]; z1 = hp.y[0]; z2 = hp.y[1];
     }
-    S.lp[send][c] = lp;
-    S.hp[send][c] = hp;
+    if (chain_lane && c == 0) {
+        // what the lane = frame phases need to know about this (instance, send)
+        float* t = table + (sub * sends + send) * 8;
+        t[0] = clp.b0; t[1] = clp.b1; t[2] = clp.b2; t[3] = chp.b0; t[4] = chp.b1; t[5] = chp.b2;
+        reinterpret_cast<int*>(t)[6] = enabled ? ((lp_on ? 1 : 0) | (hp_on ? 2 : 0) | 4) : 0;
+    }
+    float* const wrow = lds + (sub * rows + channels + r) * kFilterRow; // this lane's recurrence row
+    const float* const xrow = lds + (sub * rows + c) * kFilterRow;      // ... and its input channel
+
+    const int frames = ctx.frames;
+    // The frames of a tile are requested one tile ahead, all instances of the wavefront at once (mono / stereo: registers;
+    // more channels: one instance per wavefront or two, read in place).
+    float2 ahead[kFilterInstances];
+    auto request = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < kFilterInstances; ++k) {
+            ahead[k] = make_float2(0.0F, 0.0F);
+            if (k >= ipw || !((todo_mask >> k) & 1ULL) || base + lane >= frames) continue;
+            const float* src = src_all + static_cast<size_t>(first + k) * src_stride;
+            const size_t f = static_cast<size_t>(base + lane);
+            if (channels == 2) ahead[k] = *reinterpret_cast<const float2*>(src + f * 2);
+            else if (channels == 1) ahead[k].x = src[f];
+        }
+    };
+    request(0);
+    wave_sync(); // the table is in place
+    for (int base = 0; base < frames; base += 64) {
+        const int L = min(64, frames - base);
+        // ---- 1. the tile's frames, lane = frame ----
+        if (channels <= 2) {
+#pragma unroll
+            for (int k = 0; k < kFilterInstances; ++k) {
+                if (k >= ipw || !((todo_mask >> k) & 1ULL) || lane >= L) continue;
+                float* in_rows = lds + k * rows * kFilterRow;
+                in_rows[4 + lane] = ahead[k].x;
+                if (channels == 2) in_rows[kFilterRow + 4 + lane] = ahead[k].y;
+            }
+            if (base + 64 < frames) request(base + 64);
+        } else {
+            for (int k = 0; k < ipw; ++k) {
+                if (!((todo_mask >> k) & 1ULL) || lane >= L) continue;
+                const float* src = src_all + static_cast<size_t>(first + k) * src_stride;
+                float* in_rows = lds + k * rows * kFilterRow;
+                const size_t f = static_cast<size_t>(base + lane);
+                for (int ch = 0; ch < channels; ++ch) in_rows[ch * kFilterRow + 4 + lane] = src[f * channels + ch];
+            }
+        }
+        wave_sync();
+        // ---- 2. first shelf, feed-forward sums (lane = frame; samples 0 and 1 need the send's own input history, which the
+        // recurrence lane holds: it writes them below) ----
+        for (int k = 0; k < ipw; ++k) {
+            if (!((todo_mask >> k) & 1ULL)) continue;
+            for (int sd = 0; sd < sends; ++sd) {
+                const float* t = table + (k * sends + sd) * 8;
+                const int mode = reinterpret_cast<const int*>(t)[6];
+                if (!(mode & 4)) continue;
+                const float b0 = t[0], b1 = t[1], b2 = t[2];
+                for (int ch = 0; ch < channels; ++ch) {
+                    const float* x = lds + (k * rows + ch) * kFilterRow + 4 + lane;
+                    float v = x[0];
+                    if ((mode & 1) && lane >= 2) v = (b0 * x[0]) + (b1 * x[-1]) + (b2 * x[-2]);
+                    if (lane < L) lds[(k * rows + channels + sd * channels + ch) * kFilterRow + 4 + lane] = v;
+                }
+            }
+        }
+        wave_sync();
+        // ---- 3. first shelf, recurrence ----
+        if (enabled) {
+            const float in0 = xrow[4], in1 = xrow[5];
+            if (lp_on) {
+                wrow[4] = (clp.b0 * in0) + (clp.b1 * x1) + (clp.b2 * x2);
+                if (L > 1) wrow[5] = (clp.b0 * in1) + (clp.b1 * in0) + (clp.b2 * x1);
+            }
+            wrow[2] = y2; wrow[3] = y1; // the second shelf's feed-forward sums read its input history here
+            if (lp_on) {
+                filter_recurrence(wrow, L, clp.a1, clp.a2, y1, y2);
+            } else if (L >= 2) {
+                y1 = xrow[4 + L - 1]; y2 = xrow[4 + L - 2];
+            } else {
+                y2 = y1; y1 = in0;
+            }
+            if (L >= 2) { x1 = xrow[4 + L - 1]; x2 = xrow[4 + L - 2]; }
+            else { x2 = x1; x1 = in0; }
+        }
+        wave_sync();
+        // ---- 4. second shelf, feed-forward sums (lane = frame): read, then replace ----
+        for (int k = 0; k < ipw; ++k) {
+            if (!((todo_mask >> k) & 1ULL)) continue;
+            for (int sd = 0; sd < sends; ++sd) {
+                const float* t = table + (k * sends + sd) * 8;
+                const int mode = reinterpret_cast<const int*>(t)[6];
+                if ((mode & 6) != 6) continue; // disabled, or the second shelf is off: the row already holds its output
+                const float b0 = t[3], b1 = t[4], b2 = t[5];
+                for (int ch = 0; ch < channels; ++ch) {
+                    float* y = lds + (k * rows + channels + sd * channels + ch) * kFilterRow + 4 + lane;
+                    const float v = (b0 * y[0]) + (b1 * y[-1]) + (b2 * y[-2]);
+                    wave_sync(); // every lane has read its three samples
+                    if (lane < L) y[0] = v;
+                }
+            }
+        }
+        wave_sync();
+        // ---- 5. second shelf, recurrence ----
+        if (enabled) {
+            if (hp_on) filter_recurrence(wrow, L, chp.a1, chp.a2, z1, z2);
+            else if (L >= 2) { z1 = y1; z2 = y2; }
+            else { z2 = z1; z1 = y1; }
+        }
+        wave_sync();
+        // ---- 6. the filtered planes, lane = frame ----
+        for (int k = 0; k < ipw; ++k) {
+            if (!((todo_mask >> k) & 1ULL) || lane >= L) continue;
+            const int inst = first + k;
+            const size_t f = static_cast<size_t>(base + lane);
+            for (int sd = 0; sd < sends; ++sd) {
+                if (!(reinterpret_cast<const int*>(table + (k * sends + sd) * 8)[6] & 4)) continue;
+                float* out = filtered + static_cast<size_t>(sd) * send_floats + static_cast<size_t>(inst) * ctx.src_stride;
+                const float* zr = lds + (k * rows + channels + sd * channels) * kFilterRow + 4 + lane;
+                if (channels == 2) {
+                    *reinterpret_cast<float2*>(out + f * 2) = make_float2(zr[0], zr[kFilterRow]);
+                } else {
+                    for (int ch = 0; ch < channels; ++ch) out[f * channels + ch] = zr[ch * kFilterRow];
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (enabled) {
+        oalsfx_hist_t lp, hp;
+        lp.x[0] = x1; lp.x[1] = x2; lp.y[0] = y1; lp.y[1] = y2;
+        hp.x[0] = y1; hp.x[1] = y2; hp.y[0] = z1; hp.y[1] = z2;
+        S.lp[send][c] = lp;
+        S.hp[send][c] = hp;
+    }
 }
 
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
                          hipStream_t stream)
 {
     if (instances <= 0 || ctx.frames <= 0) return;
-    const int instances_per_wave = 64 / ((1 + ctx.slots) * ctx.channels);
-    const int waves = (instances + instances_per_wave - 1) / instances_per_wave;
+    const int ipw = filter_instances_per_wave(ctx.channels, ctx.slots);
+    const int waves = (instances + ipw - 1) / ipw;
     hipLaunchKernelGGL(k_send_filters, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, instances);
 }
 
