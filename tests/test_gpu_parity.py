@@ -538,3 +538,33 @@ def test_random_batches(seed):
     script += [("mix", 256)]
     check = sorted(rng.sample(range(n), 8))
     run_batch(fmt, rate, slots, setups, script, check_instances=check)
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO, desc.FMT_QUAD])
+def test_cooperative_workgroups_and_their_remainders(fmt):
+    """Single-slot grids follow the type-sorted list segment by segment: whole workgroups of four equalizers / distortions /
+    ring modulators run their recurrences together, the up to three left over of each type and the other types keep one
+    wavefront per instance (wave_effects_body.hpp, chain_phase).  Counts with every remainder, random properties, a ragged
+    last call, and reverbs in the same slot (the mixed grid)."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect
+    rng = random.Random(20261004 + fmt)
+    counts = {desc.EQUALIZER: 9, desc.DISTORTION: 6, desc.RING_MODULATOR: 7, desc.COMPRESSOR: 5, desc.ECHO: 2, desc.CHORUS: 1,
+              desc.EAX_REVERB: 5, desc.NULL: 1}
+    setups = [[(0, random_effect(rng, t))] for t, c in counts.items() for _ in range(c)]
+    rng.shuffle(setups)
+    run_batch(fmt, 48000, 1, setups, [("mix", 256)] * 4 + [("mix", 100)])
+    # exactly four of a type (no remainder) and three (no cooperative workgroup at all)
+    setups = [[(0, random_effect(rng, desc.EQUALIZER))] for _ in range(4)] + [[(0, random_effect(rng, desc.DISTORTION))] for _ in range(3)]
+    run_batch(fmt, 44100, 1, setups, [("mix", 256)] * 3)
+
+
+def test_send_filter_wavefronts_with_and_without_work():
+    """The send-filter pre-pass takes two consecutive instances per wavefront and skips the ones without a filter: pairs with
+    none, one or both filtered, an odd instance count, filters that come and go, more slots than one."""
+    chain = [(0, E(desc.EQUALIZER)), (1, E(desc.EAX_REVERB))]
+    script = [("mix", 256), ("send", 1, -1, 1.0, 0.5, 1.0), ("send", 4, 0, 0.8, 1.0, 0.4), ("send", 5, 1, 1.0, 0.3, 0.3), ("send", 6, -1, 0.9, 0.2, 0.7),
+              ("apply",), ("mix", 256), ("mix", 256), ("mix", 70),
+              ("send", 0, 1, 1.0, 0.6, 1.0), ("send", 1, -1, 1.0, 1.0, 1.0), ("apply",), ("mix", 256), ("mix", 1), ("mix", 256)]
+    run_batch(desc.FMT_STEREO, 48000, 2, [chain] * 7, script)
+    run_batch(desc.FMT_MONO, 48000, 2, [chain] * 3, script[:1] + [("send", 1, -1, 1.0, 0.5, 0.25), ("apply",), ("mix", 256), ("mix", 33)])
