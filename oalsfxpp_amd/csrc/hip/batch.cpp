@@ -508,12 +508,11 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     const int r = OALSFX_REVERB, e = OALSFX_EAX_REVERB;
     const int* list = b->d_lists + b->list_offset[slot][r];
     const int count = b->steady_count[slot][r] + b->steady_count[slot][e];
-    // Mono / stereo chunks of whole tiles: one launch, an instance that turns out not to be steady falls back inside it.
-    // More than two channels, or a ragged chunk: the steady-state kernel takes the whole tiles of the instances that are
-    // steady and notes per instance how far it got; the general kernel right behind it finishes every instance.
-    const bool hand_over = ctx.channels > 2 || (ctx.frames & 63) != 0;
+    // Mono / stereo: one launch, an instance that turns out not to be steady falls back inside it.  More than two channels:
+    // the steady-state kernel notes per instance whether it took it, and the general kernel right behind it does the others.
+    // (A chunk that is not a whole number of 64-frame tiles ends in a partial tile inside the steady-state kernel.)
+    const bool hand_over = ctx.channels > 2;
     KernelCtx c = ctx;
-    c.frames = ctx.frames & ~63;
     c.progress = hand_over ? b->d_progress : nullptr;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
@@ -521,7 +520,6 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
                                          b->n_short[slot] > 0, stream);
     }
     if (hand_over) {
-        c.frames = ctx.frames;
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
         oalsfx_hip::launch_reverb_general(c, slot, list, count, flags, stream);
     }
@@ -677,8 +675,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             const int rs = use_steady ? b->steady_count[s][OALSFX_REVERB] : 0, es = use_steady ? b->steady_count[s][OALSFX_EAX_REVERB] : 0;
             const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
             bool part_on[3] = {light > 0, rs + es > 0, reverbs - rs - es > 0};
-            // ring-light effects and steady reverbs in the same slot (mono / stereo, whole tiles): one grid serves both
-            const bool mixed = part_on[0] && part_on[1] && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline && !(debug_flags() & 0x80000);
+            // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
+            const bool mixed = part_on[0] && part_on[1] && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
             if (mixed) part_on[0] = false; // part 1 below launches the grid that does both
             int parts = 0;
             for (bool on : part_on) parts += on;

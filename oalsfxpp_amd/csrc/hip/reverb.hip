@@ -246,7 +246,7 @@ struct SteadyShared {
 };
 
 // The work of workgroup `group` of the cooperative kernel (its own kernel below; also one half of k_slot_mixed).
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SteadyShared<CH, NW>& sh)
 {
@@ -319,7 +319,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // ---- is this instance in its steady state for the whole buffer? ----
     unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
     unsigned short_mask = 0; // ST build: tap groups with a source inside the tile
-    bool go = valid && (frames & 63) == 0 && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
+    bool go = valid && (RG || (frames & 63) == 0) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
               (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
     const bool mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
     const float g_cur = v_gcur;
@@ -442,18 +442,19 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     auto strow = [&](int k) -> float* { return utf + ut::SIZE + 64 + k * kRow; }; // ST build: 8 hand-over rows
     float mod_f = v_modf;
     int mod_tiles = 0;
-    auto next_mod_delays = [&]() -> int {
+    auto next_mod_delays = [&](int samples_or_64) -> int { // RG: what the tile holds (a ragged call's last tile holds fewer than 64)
+        const int samples = RG ? samples_or_64 : 64;
         if (lane == 0) {
             float r = mod_f;
             const float depth = P.mod_depth, coeff = P.mod_coeff;
-            for (int i = 0; i < 64; ++i) {
+            for (int i = 0; i < samples; ++i) {
                 r = lerpf(r, depth, coeff);
                 modrow[i] = r;
             }
         }
         wave_sync();
         const float fv = modrow[lane];
-        mod_f = modrow[63];
+        mod_f = modrow[samples - 1];
         wave_sync();
         int index = (v_modidx + (mod_tiles << 6) + lane) % v_modrange;
         mod_tiles += 1;
@@ -504,7 +505,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
-    if (MD && go && mod_on) md_next = next_mod_delays();
+    if (MD && go && mod_on) md_next = next_mod_delays(min(64, frames));
     if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
     stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
@@ -519,9 +520,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // put the same phase on the same SIMD
     const int duty = (wib - group) & (NW - 1);
 
-    const int tiles = any_go ? frames >> 6 : 0; // a workgroup without a steady instance skips the cooperative loop altogether
+    const int tiles = any_go ? (RG ? (frames + 63) >> 6 : frames >> 6) : 0; // a workgroup without a steady instance skips the cooperative loop altogether
     for (int tile = 0; tile < tiles; ++tile) {
         const int pos = (tile << 6) + lane;
+        // RG, the build for calls that are not a whole number of tiles: the last tile holds fewer samples; its lanes from L on
+        // compute along but store nothing, and the recurrences stop at L.  (Its own build: with L a variable the chain loops and
+        // the predicated stores cost the whole-tile case 6 %.)
+        const int L = RG ? min(64, frames - (tile << 6)) : 64;
+        const bool act = RG ? lane < L : true;
         const unsigned t4 = static_cast<unsigned>(offset + pos) << 2;
         float o0 = 0.0F, o1 = 0.0F;
         float outv[MC ? 8 : 1] = {}; // multichannel: the output frame being accumulated
@@ -536,7 +542,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
             if (MD) {
                 md_cur = md_next;
-                if (mod_on && tile + 1 < tiles) md_next = next_mod_delays();
+                if (mod_on && tile + 1 < tiles) md_next = next_mod_delays(min(64, frames - ((tile + 1) << 6)));
             }
             if (HY) {
                 // groups with a tap closer than two tiles: requested now, after the previous tile's stores
@@ -608,7 +614,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             }
             if (lane < 4) {
                 float* ch = chain_all[wib][lane];
-                ch[coop::LPX1] = row(0, lane)[4 + 62]; ch[coop::LPX0] = row(0, lane)[4 + 63];
+                ch[coop::LPX1] = row(0, lane)[4 + L - 2]; ch[coop::LPX0] = row(0, lane)[4 + L - 1]; // L == 1: [3] is the old newest sample
             }
         }
         stamp();
@@ -619,7 +625,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
             crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
-            biquad_chain(crow1, crow2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            biquad_chain(crow1, crow2, L, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
             __builtin_amdgcn_s_setprio(0);
         }
@@ -644,7 +650,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain2_on) {
                 __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
-                biquad_chain(crow1, crow0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
+                biquad_chain(crow1, crow0, L, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -657,7 +663,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         v2f e01 = {0, 0}, e23 = {0, 0};
         float dg = 0.0F, ac = 0.0F, sx = 0.0F, sy = 0.0F;
         if (go) {
-            store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
+            if (act) store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
             wave_sync();
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
@@ -703,14 +709,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             v2f g01 = f01 + (ac * v01);
             v2f g23 = f23 + (ac * v23);
             scatter2(g01, g23, sx, sy);
-            store4(t4, OALSFX_RV_EARLY_AP, g01.x, g01.y, g23.x, g23.y);
-            store4(t4, OALSFX_RV_EARLY_LINE, v23.y, v23.x, v01.y, v01.x);
+            if (act) {
+                store4(t4, OALSFX_RV_EARLY_AP, g01.x, g01.y, g23.x, g23.y);
+                store4(t4, OALSFX_RV_EARLY_LINE, v23.y, v23.x, v01.y, v01.x);
+            }
             e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
             e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
             {
                 v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
                 scatter2(r01, r23, sx, sy);
-                store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
+                if (act) store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
                 if (ST && (short_mask & 8u)) {
                     // late taps closer than a tile to the late feed read what an earlier lane just fed
                     strow(4)[4 + lane] = r01.x; strow(5)[4 + lane] = r01.y; strow(6)[4 + lane] = r23.x; strow(7)[4 + lane] = r23.y;
@@ -739,7 +747,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
                 row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
             }
-            if (lane < 4) chain_all[wib][lane][coop::T60X] = row(0, lane)[4 + 63];
+            if (lane < 4) chain_all[wib][lane][coop::T60X] = row(0, lane)[4 + L - 1];
         }
         stamp();
         lds_barrier();
@@ -749,7 +757,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float prev = cdat[coop::T60O1];
             crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
-            first_order_chain(crow1, crow2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
+            first_order_chain(crow1, crow2, 0, L, cdat[coop::T_L2], 1.0F, false, prev);
             cdat[coop::T60O1] = prev;
             __builtin_amdgcn_s_setprio(0);
         }
@@ -773,7 +781,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
             float prev = cdat[coop::T60O2];
-            first_order_chain(crow1, crow1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+            first_order_chain(crow1, crow1, 0, L, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
             __builtin_amdgcn_s_setprio(0);
         }
@@ -807,10 +815,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
             v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
             scatter2(q01, q23, sx, sy);
-            store4(t4, OALSFX_RV_LATE_AP, q01.x, q01.y, q23.x, q23.y);
+            if (act) store4(t4, OALSFX_RV_LATE_AP, q01.x, q01.y, q23.x, q23.y);
             v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
             scatter2(r01, r23, sx, sy);
-            store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
+            if (act) store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
             const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
             if (MC) {
                 // early lines 0..3 then late lines 0..3, each into every audible channel (reference src/oalsfxpp.cpp:6142-6166)
@@ -820,7 +828,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     for (int c = 0; c < 8; ++c)
                         if (aud_out & (1ULL << (k * 8 + c))) outv[MC ? c : 0] += data[k] * utf[kMcBase + k * 8 + c];
                 }
-                if (last) {
+                if (!act) {
+                    // a lane past the end of a ragged call's last tile
+                } else if (last) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
                         if (c < nch) dst[static_cast<size_t>(pos) * nch + c] = outv[MC ? c : 0];
@@ -838,8 +848,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
                 if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
             }
-            if (MC) {
-                // stored above
+            if (MC || !act) {
+                // stored above / a lane past the end of a ragged call's last tile
             } else if (last) {
                 if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
                 else dst[pos] = o0;
@@ -885,11 +895,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ SteadyShared<CH, NW> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1494,7 +1504,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
 // first workgroups are groups of the cooperative reverb kernel (its most general build: the reverbs of such a batch rarely
 // share properties), the others run one ring-light instance per wavefront.  Two launches on two streams do the same work
 // concurrently, but ordering them against the caller's stream costs ~7 us at the fork and ~20 us at the join on this stack.
-template <int CH>
+template <int CH, bool RG>
 __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, const int* __restrict__ steady_list, int steady_count,
                                                        const int* __restrict__ light_list, int light_count, WaveSegments seg, int flags)
 {
@@ -1506,7 +1516,7 @@ __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, 
     const int steady_groups = (steady_count + 3) >> 2;
     const int group = static_cast<int>(blockIdx.x);
     if (group < steady_groups) {
-        reverb_steady_group<CH, 4, false, true, true, true>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
+        reverb_steady_group<CH, 4, false, true, true, true, RG>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
         return;
     }
     wfx::wave_block<CH>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
@@ -1518,8 +1528,11 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
     if (ctx.frames <= 0 || steady_count + light_count <= 0) return;
     const int light_blocks = seg.n > 0 ? seg.blocks() : (light_count + 3) / 4;
     const dim3 grid((steady_count + 3) / 4 + light_blocks), block(256);
-    if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
-    else OALSFX_LAUNCH((k_slot_mixed<2>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+    const bool ragged = (ctx.frames & 63) != 0;
+    if (ctx.channels == 1 && ragged) OALSFX_LAUNCH((k_slot_mixed<1, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+    else if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1, false>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+    else if (ragged) OALSFX_LAUNCH((k_slot_mixed<2, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+    else OALSFX_LAUNCH((k_slot_mixed<2, false>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
 }
 
 // Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
@@ -1530,9 +1543,16 @@ void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int c
     if (count <= 0) return;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
+    const bool ragged = (c.frames & 63) != 0; // the call ends in a partial tile: the most general build's ragged variant
     if (c.channels > 2) {
         // multichannel: the most general build only; the caller launches the general kernel on the same list right after
-        OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        if (ragged) OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        else OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        return;
+    }
+    if (ragged) {
+        if (c.channels == 1) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
+        else OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
         return;
     }
     if (c.channels == 1) {
