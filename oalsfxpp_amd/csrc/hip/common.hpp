@@ -33,9 +33,9 @@ struct KernelCtx {
     long long io_stride;                // floats between consecutive instances in dst
     long long src_stride;               // floats between consecutive instances in src / wet_src
     int* progress;                      // [instance][slots]: frames of this chunk the steady-state reverb kernel has done (all it was
-                                        // given, or none), written when it runs without its inside fallback (more than two channels,
-                                        // ragged chunks) and read by the general kernel launched right after on the same list,
-                                        // which carries on from there; nullptr otherwise
+                                        // given, or none), written when it runs without its inside fallback (more than two
+                                        // channels) and read by the general kernel launched right after on the same list, which
+                                        // carries on from there; nullptr otherwise
     unsigned long long* timeline;       // measurement only (OALSFX_DEBUG_TIMELINE): phase time stamps of sampled workgroups, else nullptr
 };
 

@@ -229,8 +229,11 @@ __device__ __forceinline__ void lds_barrier()
 // CH == 8: the multichannel build (quad .. 7.1, channel count at run time): send and pan gains live in a second table,
 // the dry mix and the panning loop over the channels, and an instance that is not steady is not taken inside the kernel
 // (its LDS would have to be sized for the general path's 64 gain ramps) but left, through ctx.progress, to the general
-// kernel that the host launches right after on the same list.  The mono / stereo builds work the same way when the host
-// hands them the whole tiles of a ragged chunk (ctx.progress set): the general kernel then finishes every instance.
+// kernel that the host launches right after on the same list (any build works that way when ctx.progress is set).
+// RG (a variant of the ST build): calls that are not a whole number of tiles.  The last tile holds L < 64 samples: its lanes
+// from L on compute along but store nothing, the recurrences and the modulation smoother stop at L, and the histories are
+// taken from sample L - 1.
+
 // LDS of one workgroup of the cooperative kernel
 template <int CH, int NW>
 struct SteadyShared {
