@@ -568,3 +568,27 @@ def test_send_filter_wavefronts_with_and_without_work():
               ("send", 0, 1, 1.0, 0.6, 1.0), ("send", 1, -1, 1.0, 1.0, 1.0), ("apply",), ("mix", 256), ("mix", 1), ("mix", 256)]
     run_batch(desc.FMT_STEREO, 48000, 2, [chain] * 7, script)
     run_batch(desc.FMT_MONO, 48000, 2, [chain] * 3, script[:1] + [("send", 1, -1, 1.0, 0.5, 0.25), ("apply",), ("mix", 256), ("mix", 33)])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_every_build_of_the_steady_kernel(fmt):
+    """The host picks the steady-state kernel's build per launch from what the listed instances need: only far taps (plain),
+    a tap between one and two tiles (HY), a modulated late line (MD), anything shorter (ST), a ragged call (RG).  One batch
+    per build, so that each is launched, long enough to be on it for several buffers."""
+    from oalsfxpp_amd import lib
+
+    def span(i):  # shortest tap distance of preset i, in samples, and whether its late line is modulated
+        p = lib.derive_slot(fmt, 48000, lib.effect_normalized(preset_effect(i))).u.reverb
+        taps = list(p.early_tap) + list(p.early_ap_off) + list(p.early_line_off) + [t - p.late_feed_tap for t in p.late_tap] + \
+            list(p.late_ap_off) + list(p.late_line_off)
+        return min(taps), p.mod_depth != 0.0
+
+    spans = {i: span(i) for i in range(113)}
+    plain = [i for i, (d, m) in spans.items() if d >= 128 and not m][:3]
+    close = [i for i, (d, m) in spans.items() if 64 <= d < 128 and not m][:3]
+    modulated = [i for i, (d, m) in spans.items() if d >= 64 and m][:3]
+    assert plain and close and modulated, (plain, close, modulated)
+    script = [("mix", 256)] * 6
+    for picks in (plain, close, modulated):
+        run_batch(fmt, 48000, 1, [[(0, preset_effect(i))] for i in picks], script)
+    run_batch(fmt, 48000, 1, [[(0, preset_effect(i))] for i in plain + modulated], script + [("mix", 100), ("mix", 333), ("mix", 65)])
