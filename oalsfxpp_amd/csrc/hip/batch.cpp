@@ -499,7 +499,7 @@ constexpr int kTimedWaveEffects = -1; // TimedLaunch::type of the merged launch 
 constexpr int kTimedMixed = -2;       // ... of the grid that serves ring-light effects and steady reverbs of a slot together
 
 // Can the steady-state kernel be used for this chunk at all?
-bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 64 && !(debug_flags() & 8); }
+bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 1 && !(debug_flags() & 8); } // any call size: a short call is one partial tile
 
 // One steady-state launch for the believed-steady instances of both reverb types (adjacent in the list; the kernel reads
 // the type per instance).
