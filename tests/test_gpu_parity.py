@@ -353,12 +353,17 @@ def test_full_size_config4_sample():
 def test_denormal_signals():
     """Signals around and below the smallest normal float: the reference runs on x86 without flush-to-zero, and so do the
     kernels (fp32 denormals are on by default on gfx9); a flush anywhere would show up as a bit difference."""
+    # five of each type: the filter-heavy ones then form a cooperative workgroup and a remainder; every third instance has
+    # shelf filters on its sends
     setups = [[(0, E(t))] for t in (desc.EAX_REVERB, desc.REVERB, desc.ECHO, desc.EQUALIZER, desc.CHORUS, desc.DISTORTION, desc.COMPRESSOR,
-                                    desc.RING_MODULATOR)]
+                                    desc.RING_MODULATOR) for _ in range(5)]
     n = len(setups)
     with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
         for i, eff in enumerate(setups):
             b.set_effect(0, eff[0][1], first=i, count=1)
+            if i % 3 == 0:
+                b.set_send_props(-1, 1.0, 0.5, 0.7, first=i, count=1)
+                b.set_send_props(0, 0.9, 0.3, 1.0, first=i, count=1)
         b.apply_changes()
         shadows = [OracleShadow(b, i) for i in range(n)]
         for k, scale in enumerate([1e-36, 1e-37, 1e-38, 3e-39, 1e-40, 1e-42, 0.0, 0.0, 1e-38, 0.0]):
@@ -374,11 +379,14 @@ def test_denormal_signals():
 def test_huge_infinite_and_nan_inputs():
     """Garbage in, the same garbage out: very large samples, infinities and NaNs take the same path through every effect as
     in the reference (std::min / std::max argument order included); NaN payloads and signs are not compared."""
-    types = (desc.EAX_REVERB, desc.ECHO, desc.EQUALIZER, desc.CHORUS, desc.DISTORTION, desc.COMPRESSOR, desc.RING_MODULATOR, desc.DEDICATED_DIALOG)
-    n = len(types)
+    types = (desc.EAX_REVERB, desc.ECHO, desc.EQUALIZER, desc.CHORUS, desc.DISTORTION, desc.COMPRESSOR, desc.RING_MODULATOR, desc.DEDICATED_DIALOG) * 5
+    n = len(types)  # five of each: cooperative workgroups and remainders; every third instance with shelf filters on its sends
     with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
         for i, t in enumerate(types):
             b.set_effect_type(0, t, first=i, count=1)
+            if i % 3 == 0:
+                b.set_send_props(-1, 1.0, 0.5, 0.7, first=i, count=1)
+                b.set_send_props(0, 0.9, 0.3, 1.0, first=i, count=1)
         b.apply_changes()
         shadows = [OracleShadow(b, i) for i in range(n)]
         for k in range(6):
