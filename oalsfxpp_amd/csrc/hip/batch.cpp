@@ -540,7 +540,7 @@ bool cooperative_type(int type)
 {
     // (the compressor's follower goes through chain_phase too, but a wavefront's own is as fast: it is short, and what a
     // workgroup saves in instructions it loses at the two barriers)
-    return type == OALSFX_DISTORTION || type == OALSFX_EQUALIZER || type == OALSFX_RING_MODULATOR;
+    return type == OALSFX_DISTORTION || type == OALSFX_ECHO || type == OALSFX_EQUALIZER || type == OALSFX_RING_MODULATOR;
 }
 
 // The ring-light types of a slot from `first_type` on as segments of one grid: per type the whole workgroups (cooperative

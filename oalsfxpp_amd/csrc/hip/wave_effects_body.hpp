@@ -453,13 +453,27 @@ struct EchoW {
     int offset;
     float n_t1, n_t2;   // taps of the next tile, requested one tile ahead when both taps are at least two tiles long
     bool have_next;
+    int block;          // samples per sub-block: no longer than the shorter tap (in a cooperative workgroup: than anybody's)
     __device__ void init(const Inst& I)
     {
+        const auto& p = I.sp->u.echo;
         offset = I.ss->u.echo.offset;
         n_t1 = n_t2 = 0.0F;
         have_next = false;
-        if (I.lane == 0) load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
+        block = max(1, min(64, min(p.tap1, p.tap2)));
+        if (I.lane == 0) {
+            load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
+            float* yrow = I.lds + kRow; // the recurrence's coefficients travel with its row
+            yrow[0] = p.filter.a1; yrow[1] = p.filter.a2;
+            reinterpret_cast<int*>(I.lds + kCoefBase)[0] = block;
+        }
         wave_sync();
+        if (I.coop) {
+            // the four instances walk the tile in the same sub-blocks, so that their recurrences can share a wavefront
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) block = min(block, reinterpret_cast<const int*>(I.group_lds + k * I.group_stride + kCoefBase)[0]);
+        }
     }
     template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
     {
@@ -468,7 +482,6 @@ struct EchoW {
         const unsigned mask = static_cast<unsigned>(p.ring_len - 1);
         const Coef c = coef(p.filter);
         const int o = offset + lane;
-        const int block = max(1, min(64, min(p.tap1, p.tap2)));
         float* xrow = I.lds;
         float* yrow = I.lds + kRow;
         float* wrow = I.lds + 2 * kRow; // what this tile writes to the ring; taps shorter than the tile read it here
@@ -500,9 +513,10 @@ struct EchoW {
                 const float* x = xrow + 4 + lane;
                 yrow[4 + lane] = ((x[0] * c.b0) + (x[-1] * c.b1)) + (x[-2] * c.b2);
             }
-            wave_sync();
-            if (lane == 0) chain_biquad(yrow, s, e, c.a1, c.a2);
-            wave_sync();
+            chain_phase(I, 1, [s, e](float* lds, int) {
+                float* row = lds + kRow;
+                chain_biquad(row, s, e, row[0], row[1]);
+            });
             if (mine) wrow[4 + lane] = yrow[4 + lane] * p.feed_gain;
             wave_sync();
         }
