@@ -26,6 +26,7 @@ DEVICE = ["--offload-arch=gfx950", "-x", "hip"]  # fp32 denormals stay on (the g
 # per-source additions
 EXTRA = {
     "hip/wave_effects.hip": ["-fno-slp-vectorize"],
+    "hip/reverb.hip": ["-fno-slp-vectorize"],
 }
 
 
