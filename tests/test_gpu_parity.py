@@ -86,7 +86,7 @@ def test_eax_midstream_change_and_odd_sizes():
 
 
 def test_eax_low_and_high_rates():
-    for rate in (8000, 11025, 22050, 96000):
+    for rate in (8000, 11025, 22050, 96000, 192000):
         run_batch(desc.FMT_STEREO, rate, 1, [[(0, E(desc.EAX_REVERB))], [(0, preset_effect(112))], [(0, E(desc.EAX_REVERB, density=0.0, modulation_depth=1.0))]],
                   [("mix", 256)] * 6)
 
