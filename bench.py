@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"],
                     help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain) or configs[3] "
                          "(11 effect types, randomised properties; 8192 instances unless --instances is given)")
-    ap.add_argument("--host-io", type=int, default=0, metavar="K",
+    ap.add_argument("--host-io", type=int, default=10, metavar="K",
                     help="after the timed region, also time K steps through oalsfx_batch_mix (host buffers, PCIe both ways)")
     args = ap.parse_args()
 
@@ -297,8 +297,8 @@ def main():
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = t.get("source")
 
-    if args.host_io > 0:
-        # PCIe-inclusive rate (never `value`): pinned host buffers through oalsfx_batch_mix, synchronous per step
+    if args.host_io > 0 and world == 1:
+        # PCIe-inclusive rate (never `value`; single-GPU runs only): pinned host buffers through oalsfx_batch_mix, synchronous per step
         hsrc = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).uniform_(-1, 1).pin_memory()
         hdst = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).pin_memory()
         import ctypes as C
