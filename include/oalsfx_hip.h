@@ -99,6 +99,17 @@ int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_ind
  * grid that serves a slot's ring-light effects and steady reverbs together (k_slot_mixed: mono / stereo, whole tiles). */
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable);
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms);
+/* The same launches one by one: up to `max_samples` durations in microseconds (event pair, uncorrected) into `out_us`; returns the
+ * number of timed launches of that type since enable (-1 on error).  bench.py takes its median from these. */
+int oalsfx_batch_kernel_timing_samples(oalsfx_batch* b, int effect_type, double* out_us, int max_samples);
+/* How the next mix call would lay out `slot` (pending property changes and read-backs folded in first): counts[0] instances on the
+ * ring-light kernels, [1] reverbs proven steady (the builds without fallback), [2] reverbs believed steady, [3] reverbs on
+ * the general kernel.  Nothing the reference has a counterpart for; tests and bench.py use it to say which kernel they measured. */
+int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4]);
+/* Symbol of the steady-state reverb kernel launched last, with its template arguments as rocprofv3 prints them ("" before the first). */
+const char* oalsfx_batch_last_reverb_kernel(const oalsfx_batch* b);
+/* PCI bus id ("0000:c1:00.0") of a HIP device ordinal, for benchmark records that must show N distinct GPUs.  Returns 1 on success. */
+int oalsfx_device_pci_bus_id(int device_id, char* out, int len);
 /* What such an event pair measures beyond the kernel: the average elapsed time of `repeats` pairs with nothing between them
  * on the batch's stream (about 4.4 us on MI355X).  bench.py reports its kernel time with this subtracted, which agrees with
  * rocprofv3's kernel trace of the same run to 2 %, and keeps the raw figure next to it. */

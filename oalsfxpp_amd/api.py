@@ -145,6 +145,23 @@ class Batch:
         self._check(self._lib.oalsfx_batch_event_overhead(self._h, repeats, C.byref(us)))
         return us.value
 
+    def kernel_timing_samples(self, effect_type, max_samples=4096):
+        """Per-launch durations (microseconds, raw event pairs) of the timed launches of `effect_type`."""
+        buf = (C.c_double * max_samples)()
+        n = self._lib.oalsfx_batch_kernel_timing_samples(self._h, effect_type, buf, max_samples)
+        self._check(n >= 0)
+        return list(buf[:min(n, max_samples)])
+
+    def plan(self, slot=0):
+        """(ring-light, reverbs proven steady, reverbs believed steady, reverbs on the general kernel) for the next mix call."""
+        c = (C.c_int * 4)()
+        self._check(self._lib.oalsfx_batch_plan(self._h, slot, c))
+        return tuple(c)
+
+    @property
+    def last_reverb_kernel(self):
+        return (self._lib.oalsfx_batch_last_reverb_kernel(self._h) or b"").decode()
+
     def kernel_timing_read(self, effect_type):
         n, ms = C.c_int(0), C.c_double(0.0)
         self._check(self._lib.oalsfx_batch_kernel_timing_read(self._h, effect_type, C.byref(n), C.byref(ms)))

@@ -41,7 +41,7 @@ struct RingPool {
 
 struct TimedLaunch { hipEvent_t start, stop; int type; };
 
-constexpr int kSideStreams = 2; // ring-light effects, steady-state reverbs, general reverbs: three kernel groups side by side at most
+constexpr int kSideStreams = 3; // ring-light effects, proven-steady reverbs, believed-steady reverbs, general reverbs: four kernel groups side by side at most
 
 } // namespace
 
@@ -69,6 +69,15 @@ struct oalsfx_batch {
     bool modulated[OALSFX_MAX_SLOTS] = {};        // some reverb of the slot has, or had, a modulated late line (sticky: the depth
                                                   // smoother keeps moving long after the depth is set to 0)
     int n_filtered = 0;                           // instances with a send filter switched on
+    // What the host *knows* about the reverb slots (as opposed to believes): a slot is proven steady once the device has reported it
+    // exactly settled (d_exact, read back without ever waiting for the stream) and nothing has been uploaded for its instance since.
+    std::vector<uint8_t> proven;                  // [n*slots]
+    std::vector<uint32_t> updated_gen;            // [n*slots] upload generation of the last parameter upload that touched the slot's instance
+    std::vector<uint32_t> inst_epoch;             // [n] stamps the hot records: bumped with every upload that touches the instance
+    uint32_t upload_gen = 0;
+    bool exact_wanted = false;                    // something changed that may let the next read-back prove more slots
+    bool exact_pending = false;                   // a read-back of d_exact is in flight (ev_exact)
+    uint32_t exact_gen = 0;                       // upload generation the read-back in flight was taken at
     std::vector<int> dirty_list;
     bool lists_dirty = true;
     // Instances a setter has written since they were last applied: apply_changes() visits only these (for the others the
@@ -87,12 +96,23 @@ struct oalsfx_batch {
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]
     int* d_progress = nullptr;                    // [n*slots] hand-off from the steady-state reverb kernel to the general kernel behind it
+    unsigned* d_hot = nullptr;                    // [n*slots][hot::SIZE] start records of the proven-steady reverb kernel
+    unsigned* d_inst_epoch = nullptr;             // [n]
+    unsigned* d_exact = nullptr;                  // [n*slots] "exactly settled" as the reverb kernels left it
+    unsigned* h_exact = nullptr;                  // pinned copy of d_exact, filled by the read-back
+    unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
+    unsigned* d_fault = nullptr;                  // device address of h_fault
+    hipEvent_t ev_exact = nullptr;
     // Per slot the list is: ring-light types in ascending order (list_offset / list_count per type), then the reverb instances
-    // believed steady (reverb, EAX reverb: list_offset / steady_count), then every other reverb instance of both types
-    // (general_offset / general_count).  list_count of a reverb type counts all its instances.
+    // proven steady (reverb, EAX reverb: steady_offset / fast_count), those believed steady (reverb, EAX reverb: slow_count), then
+    // every other reverb instance of both types (general_offset / general_count).  list_count of a reverb type counts all its
+    // instances.
     int list_offset[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
-    int steady_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
+    int steady_offset[OALSFX_MAX_SLOTS] = {};     // start of the steady region: the proven instances, then the believed ones
+    int fast_count[OALSFX_MAX_SLOTS] = {};        // proven steady (both reverb types)
+    int fast_first[OALSFX_MAX_SLOTS] = {};        // >= 0: the proven part of the list is the instance range fast_first, fast_first + 1, ...
+    int slow_count[OALSFX_MAX_SLOTS] = {};        // believed steady (both reverb types)
     int general_offset[OALSFX_MAX_SLOTS] = {};
     int general_count[OALSFX_MAX_SLOTS] = {};
     std::map<size_t, RingPool> pools;
@@ -112,6 +132,7 @@ struct oalsfx_batch {
     hipEvent_t ev_uploaded = nullptr;             // parameter uploads of the batch's own stream -> a caller's launch stream
     hipEvent_t ev_mixed = nullptr;                // last launch on a caller's stream -> parameter uploads that overwrite what it reads
     hipStream_t last_launch_stream = nullptr;
+    const char* last_steady_kernel = "";          // symbol of the last steady-state reverb launch
 
     hipStream_t stream = nullptr;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
@@ -243,7 +264,7 @@ void advance_settling(oalsfx_batch* b, int frames)
         b->since_update[idx] = std::min(b->since_update[idx] + frames, kSettleFrames);
         if (b->since_update[idx] < kSettleFrames) { b->settling[keep++] = idx; continue; }
         b->in_settling[idx] = 0;
-        if (b->slot_class[idx] & kClassSteady) b->lists_dirty = true;
+        if (b->slot_class[idx] & kClassSteady) { b->lists_dirty = true; b->exact_wanted = true; }
     }
     b->settling.resize(keep);
 }
@@ -287,7 +308,9 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     std::map<size_t, int> need; // size class -> slabs needed
     std::vector<size_t> restarted;
     std::vector<int> up_params, up_state, up_source; // indices of the records to upload
+    std::vector<uint32_t> up_epoch;                  // new epochs of the instances in up_source
     bool any_type_change = false;
+    if (!b->dirty_list.empty()) b->upload_gen += 1;
 
     // a caller's stream may still be running kernels that read what is about to be overwritten
     if (b->last_launch_stream && b->last_launch_stream != b->stream) {
@@ -343,6 +366,15 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
             derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, sp);
             b->n_filtered += static_cast<int>(has_filter(sp)) - static_cast<int>(before);
             up_source.push_back(i);
+            // whatever the device knew about this instance is out of date: its hot records (new epoch) and the proof that its reverbs
+            // are steady (a send change alone leaves them steady, which the next read-back will confirm)
+            up_epoch.push_back(++b->inst_epoch[i]);
+            for (int s = 0; s < b->slots; ++s) {
+                const size_t idx = static_cast<size_t>(i) * b->slots + s;
+                if (b->proven[idx]) { b->proven[idx] = 0; b->lists_dirty = true; }
+                b->updated_gen[idx] = b->upload_gen;
+            }
+            b->exact_wanted = true;
         }
         b->inst_dirty[i] = 0;
     }
@@ -388,30 +420,38 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     std::vector<int> lists;
     if (rebuild_lists) {
         lists.resize(total);
-        constexpr int kBuckets = OALSFX_REVERB + 4; // ring-light types, then reverb / EAX reverb believed steady, then the other reverbs
+        // ring-light types, then per reverb type: proven steady, believed steady, the others
+        constexpr int kFast = OALSFX_REVERB, kSlow = OALSFX_REVERB + 2, kGeneral = OALSFX_REVERB + 4, kBuckets = OALSFX_REVERB + 6;
         for (int s = 0; s < b->slots; ++s) {
             int count[kBuckets] = {};
             auto bucket = [&](int i) {
                 const size_t idx = static_cast<size_t>(i) * b->slots + s;
                 const int t = b->h_params[idx].type;
                 if (t < OALSFX_REVERB) return t;
-                return OALSFX_REVERB + (t - OALSFX_REVERB) + (reverb_settled(b, idx) ? 0 : 2);
+                const int cls = !reverb_settled(b, idx) ? kGeneral : b->proven[idx] ? kFast : kSlow;
+                return cls + (t - OALSFX_REVERB);
             };
             for (int i = 0; i < b->n; ++i) count[bucket(i)] += 1;
             int start[kBuckets];
             int off = s * b->n;
             for (int k = 0; k < kBuckets; ++k) { start[k] = off; off += count[k]; }
             for (int t = 0; t < OALSFX_REVERB; ++t) { b->list_offset[s][t] = start[t]; b->list_count[s][t] = count[t]; }
-            for (int t : {OALSFX_REVERB, OALSFX_EAX_REVERB}) {
-                b->list_offset[s][t] = start[t];
-                b->steady_count[s][t] = count[t];
-                b->list_count[s][t] = count[t] + count[t + 2];
+            for (int t = 0; t < 2; ++t) {
+                b->list_offset[s][OALSFX_REVERB + t] = start[kFast]; // the reverb region as a whole (its types interleave by class)
+                b->list_count[s][OALSFX_REVERB + t] = count[kFast + t] + count[kSlow + t] + count[kGeneral + t];
             }
-            b->general_offset[s] = start[OALSFX_REVERB + 2];
-            b->general_count[s] = count[OALSFX_REVERB + 2] + count[OALSFX_REVERB + 3];
+            b->steady_offset[s] = start[kFast];
+            b->fast_count[s] = count[kFast] + count[kFast + 1];
+            b->slow_count[s] = count[kSlow] + count[kSlow + 1];
+            b->general_offset[s] = start[kGeneral];
+            b->general_count[s] = count[kGeneral] + count[kGeneral + 1];
             int fill[kBuckets];
             for (int k = 0; k < kBuckets; ++k) fill[k] = start[k];
             for (int i = 0; i < b->n; ++i) lists[fill[bucket(i)]++] = i;
+            // a proven part that is simply a range of instances needs no list on the device
+            b->fast_first[s] = b->fast_count[s] > 0 ? lists[start[kFast]] : -1;
+            for (int k = 1; k < b->fast_count[s]; ++k)
+                if (lists[start[kFast] + k] != b->fast_first[s] + k) { b->fast_first[s] = -1; break; }
         }
         b->lists_dirty = false;
     }
@@ -426,6 +466,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     const size_t o_sr = off; off += padded(n_s * sizeof(oalsfx_slot_state));
     const size_t o_ci = off; off += padded(n_src * sizeof(int));
     const size_t o_cr = off; off += padded(n_src * sizeof(oalsfx_source_params));
+    const size_t o_ep = off; off += padded(n_src * sizeof(uint32_t));
     const size_t o_rt = off; off += rings_changed ? padded(total * sizeof(float*)) : 0;
     const size_t o_li = off; off += rebuild_lists ? padded(total * sizeof(int)) : 0;
     if (off > 0) {
@@ -437,6 +478,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         for (size_t k = 0; k < n_s; ++k) std::memcpy(st->host + o_sr + k * sizeof(oalsfx_slot_state), &b->h_state_init[up_state[k]], sizeof(oalsfx_slot_state));
         if (n_src) std::memcpy(st->host + o_ci, up_source.data(), n_src * sizeof(int));
         for (size_t k = 0; k < n_src; ++k) std::memcpy(st->host + o_cr + k * sizeof(oalsfx_source_params), &b->h_source[up_source[k]], sizeof(oalsfx_source_params));
+        if (n_src) std::memcpy(st->host + o_ep, up_epoch.data(), n_src * sizeof(uint32_t));
         if (rings_changed) std::memcpy(st->host + o_rt, b->h_rings.data(), total * sizeof(float*));
         if (rebuild_lists) std::memcpy(st->host + o_li, lists.data(), total * sizeof(int));
         if (!b->hip_ok(hipMemcpyAsync(st->dev, st->host, off, hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(parameters)")) return false;
@@ -446,6 +488,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         launch_scatter_records(b->d_params, sizeof(oalsfx_slot_params), st->dev + o_pr, reinterpret_cast<const int*>(st->dev + o_pi), static_cast<int>(n_p), b->stream);
         launch_scatter_records(b->d_state, sizeof(oalsfx_slot_state), st->dev + o_sr, reinterpret_cast<const int*>(st->dev + o_si), static_cast<int>(n_s), b->stream);
         launch_scatter_records(b->d_source, sizeof(oalsfx_source_params), st->dev + o_cr, reinterpret_cast<const int*>(st->dev + o_ci), static_cast<int>(n_src), b->stream);
+        launch_scatter_records(b->d_inst_epoch, sizeof(uint32_t), st->dev + o_ep, reinterpret_cast<const int*>(st->dev + o_ci), static_cast<int>(n_src), b->stream);
         if (rings_changed && !b->hip_ok(hipMemcpyAsync(b->d_rings, st->dev + o_rt, total * sizeof(float*), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(ring table)")) return false;
         if (rebuild_lists && !b->hip_ok(hipMemcpyAsync(b->d_lists, st->dev + o_li, total * sizeof(int), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(lists)")) return false;
         if (!b->hip_ok(hipGetLastError(), "parameter upload")) return false;
@@ -501,23 +544,24 @@ constexpr int kTimedMixed = -2;       // ... of the grid that serves ring-light 
 // Can the steady-state kernel be used for this chunk at all?
 bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 1 && !(debug_flags() & 8); } // any call size: a short call is one partial tile
 
-// One steady-state launch for the believed-steady instances of both reverb types (adjacent in the list; the kernel reads
-// the type per instance).
-void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
+// One steady-state launch for steady instances of both reverb types (adjacent in the list; the kernel reads the type per
+// instance): the proven ones (`proven`: the builds without steady-state test and general path), the believed ones, or both
+// together through the believing builds.
+void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, int offset, int count, bool proven, hipStream_t stream)
 {
-    const int r = OALSFX_REVERB, e = OALSFX_EAX_REVERB;
-    const int* list = b->d_lists + b->list_offset[slot][r];
-    const int count = b->steady_count[slot][r] + b->steady_count[slot][e];
+    const int* list = b->d_lists + offset;
     // Mono / stereo: one launch, an instance that turns out not to be steady falls back inside it.  More than two channels:
     // the steady-state kernel notes per instance whether it took it, and the general kernel right behind it does the others.
     // (A chunk that is not a whole number of 64-frame tiles ends in a partial tile inside the steady-state kernel.)
     const bool hand_over = ctx.channels > 2;
     KernelCtx c = ctx;
     c.progress = hand_over ? b->d_progress : nullptr;
+    c.list_first = proven ? b->fast_first[slot] : -1;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
-        oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0, b->modulated[slot],
-                                         b->n_short[slot] > 0, stream);
+        const char* name = oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0,
+                                                            b->modulated[slot], b->n_short[slot] > 0, proven, stream);
+        if (name) b->last_steady_kernel = name;
     }
     if (hand_over) {
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
@@ -526,11 +570,11 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
 }
 
 // The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of
-// the slot when the steady-state kernel cannot be used for this chunk (the two regions are adjacent in the list).
+// the slot when the steady-state kernel cannot be used for this chunk (the regions are adjacent in the list).
 void launch_reverb_general_part(oalsfx_batch* b, bool everything, const KernelCtx& ctx, int slot, int flags, hipStream_t stream)
 {
-    const int offset = everything ? b->list_offset[slot][OALSFX_REVERB] : b->general_offset[slot];
-    const int count = b->general_count[slot] + (everything ? b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB] : 0);
+    const int offset = everything ? b->steady_offset[slot] : b->general_offset[slot];
+    const int count = b->general_count[slot] + (everything ? b->fast_count[slot] + b->slow_count[slot] : 0);
     ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
     oalsfx_hip::launch_reverb_general(ctx, slot, b->d_lists + offset, count, flags, stream);
 }
@@ -589,11 +633,11 @@ void launch_mixed_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     const int first_type = null_has_duty ? OALSFX_NULL : OALSFX_NULL + 1;
     oalsfx_hip::WaveSegments seg;
     const int light = wave_segments(b, slot, first_type, seg);
-    const int steady = b->steady_count[slot][OALSFX_REVERB] + b->steady_count[slot][OALSFX_EAX_REVERB];
+    const int steady = b->fast_count[slot] + b->slow_count[slot];
     KernelCtx c = ctx;
     c.progress = nullptr; // an instance that turns out not to be steady falls back inside the grid
     ScopedTiming timing(b, kTimedMixed, stream);
-    oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->list_offset[slot][OALSFX_REVERB], steady, b->d_lists + b->list_offset[slot][first_type], light,
+    oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->steady_offset[slot], steady, b->d_lists + b->list_offset[slot][first_type], light,
                                   seg, flags, stream);
 }
 
@@ -605,8 +649,32 @@ int reverb_free_run(const oalsfx_batch* b, int slot)
     return n;
 }
 
+// A finished read-back of the "exactly settled" flags turns believed-steady reverbs into proven ones.  Never waits: an event that
+// has not completed yet is looked at again by the next call.
+void poll_exact(oalsfx_batch* b)
+{
+    if (!b->exact_pending || hipEventQuery(b->ev_exact) != hipSuccess) return;
+    b->exact_pending = false;
+    const size_t total = static_cast<size_t>(b->n) * b->slots;
+    for (size_t idx = 0; idx < total; ++idx) {
+        // the flag describes the slot as of the read-back's call: usable when nothing was uploaded for the instance after that
+        if (b->proven[idx] || !b->h_exact[idx] || b->updated_gen[idx] > b->exact_gen || !reverb_settled(b, idx)) continue;
+        b->proven[idx] = 1;
+        b->lists_dirty = true;
+    }
+}
+
+// Reported by the calls that wait for the stream: a proven-steady launch found an instance that was not steady (it left it
+// unprocessed).  The host's bookkeeping makes that impossible; if it happens anyway it must not pass silently.
+bool check_fault(oalsfx_batch* b)
+{
+    if (!b->h_fault || *b->h_fault == 0) return true;
+    return b->fail("Internal error: a reverb instance listed as proven steady was not; its buffer was left unprocessed.");
+}
+
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
 {
+    poll_exact(b);
     if (!sync_params(b, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
     b->timing = b->timing_every > 0 && (b->mix_calls++ % b->timing_every) == 0;
@@ -629,6 +697,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.source_state = b->d_source_state;
     ctx.mixbuf = b->d_mixbuf;
     ctx.timeline = b->d_timeline;
+    ctx.hot = b->d_hot;
+    ctx.inst_epoch = b->d_inst_epoch;
+    ctx.exact = b->d_exact;
+    ctx.fault = b->d_fault;
+    ctx.list_first = -1;
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
@@ -672,19 +745,23 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state reverb kernel and the general
             // reverb kernel
             const bool use_steady = steady_kernel_usable(ctx);
-            const int rs = use_steady ? b->steady_count[s][OALSFX_REVERB] : 0, es = use_steady ? b->steady_count[s][OALSFX_EAX_REVERB] : 0;
+            const int steady = use_steady ? b->fast_count[s] + b->slow_count[s] : 0;
             const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
-            bool part_on[3] = {light > 0, rs + es > 0, reverbs - rs - es > 0};
             // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
-            const bool mixed = part_on[0] && part_on[1] && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
-            if (mixed) part_on[0] = false; // part 1 below launches the grid that does both
+            const bool mixed = light > 0 && steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
+            // the proven-steady builds: mono / stereo, whole tiles, a launch of their own
+            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && !(debug_flags() & 0x200000);
+            const int fast = use_fast ? b->fast_count[s] : 0;
+            // parts: ring-light effects | proven-steady reverbs | believed-steady reverbs (all steady ones where the proven builds
+            // are not in play) | general reverbs
+            bool part_on[4] = {light > 0 && !mixed, fast > 0, steady - fast > 0, reverbs - steady > 0};
             int parts = 0;
             for (bool on : part_on) parts += on;
             const bool fork = parts > 1 && !(debug_flags() & 0x20000);
             if (fork && !b->hip_ok(hipEventRecord(b->ev_fork, stream), "hipEventRecord")) return false;
             int side = 0;
             bool main_taken = false;
-            for (int g = 0; g < 3; ++g) {
+            for (int g = 0; g < 4; ++g) {
                 if (!part_on[g]) continue;
                 hipStream_t gs = stream;
                 if (fork && main_taken) {
@@ -693,10 +770,12 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 }
                 if (g == 0) {
                     launch_wave_group(b, ctx, s, flags, gs);
-                } else if (g == 1 && mixed) {
-                    launch_mixed_part(b, ctx, s, flags, gs);
                 } else if (g == 1) {
-                    launch_reverb_steady_part(b, ctx, s, flags, gs);
+                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], fast, true, gs);
+                } else if (g == 2 && mixed) {
+                    launch_mixed_part(b, ctx, s, flags, gs);
+                } else if (g == 2) {
+                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s] + fast, steady - fast, false, gs);
                 } else {
                     launch_reverb_general_part(b, !use_steady, ctx, s, flags, gs);
                 }
@@ -711,6 +790,15 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         done += n;
     }
     advance_settling(b, frames);
+    if (b->exact_wanted && !b->exact_pending) {
+        // what this call's kernels found out about the reverbs that are not proven steady yet, fetched behind them
+        const size_t total = static_cast<size_t>(b->n) * b->slots;
+        if (!b->hip_ok(hipMemcpyAsync(b->h_exact, b->d_exact, total * sizeof(unsigned), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync(exact)")) return false;
+        if (!b->hip_ok(hipEventRecord(b->ev_exact, stream), "hipEventRecord")) return false;
+        b->exact_pending = true;
+        b->exact_wanted = false;
+        b->exact_gen = b->upload_gen;
+    }
     b->last_launch_stream = stream;
     if (stream != b->stream && !b->hip_ok(hipEventRecord(b->ev_mixed, stream), "hipEventRecord")) return false;
     return b->hip_ok(hipGetLastError(), "kernel launch");
@@ -763,6 +851,9 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->since_update.assign(total, 0);
     b->slot_class.assign(total, 0);
     b->in_settling.assign(total, 0);
+    b->proven.assign(total, 0);
+    b->updated_gen.assign(total, 0);
+    b->inst_epoch.assign(n_instances, 1); // a zero-filled hot record never carries a valid stamp
     for (int i = 0; i < n_instances; ++i) {
         b->inst[i].initialize(effect_count);
         mark_dirty(b, i);
@@ -785,6 +876,17 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hot), total * oalsfx_hip::hot::SIZE * sizeof(unsigned)), "hipMalloc(hot records)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_hot, 0, total * oalsfx_hip::hot::SIZE * sizeof(unsigned), b->stream), "hipMemsetAsync(hot records)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_inst_epoch), n_instances * sizeof(unsigned)), "hipMalloc(epochs)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_inst_epoch, 0, n_instances * sizeof(unsigned), b->stream), "hipMemsetAsync(epochs)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_exact, 0, total * sizeof(unsigned), b->stream), "hipMemsetAsync(exact)");
+    ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_exact), total * sizeof(unsigned)), "hipHostMalloc(exact)");
+    ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_fault), sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(fault)");
+    if (ok) *b->h_fault = 0;
+    ok = ok && b->hip_ok(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_fault), b->h_fault, 0), "hipHostGetDevicePointer");
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_exact, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
     if (ok && std::getenv("OALSFX_DEBUG_TIMELINE")) {
@@ -806,6 +908,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     if (b->stream) hipStreamSynchronize(b->stream);
     for (int k = 0; k < kSideStreams; ++k)
         if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
+    if (b->exact_pending) hipEventSynchronize(b->ev_exact); // a read-back on a caller's stream still writes to h_exact
     if (b->d_timeline) {
         // phase stamps of the last steady-state reverb launch, for scripts/timeline.py
         std::vector<unsigned long long> h(kTimelineBytes / sizeof(unsigned long long));
@@ -818,6 +921,10 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (void* c : b->chunks) hipFree(c);
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    hipFree(b->d_hot); hipFree(b->d_inst_epoch); hipFree(b->d_exact);
+    if (b->h_exact) (void)hipHostFree(b->h_exact);
+    if (b->h_fault) (void)hipHostFree(b->h_fault);
+    if (b->ev_exact) hipEventDestroy(b->ev_exact);
     for (int k = 0; k < kSideStreams; ++k) {
         if (b->side_stream[k]) hipStreamDestroy(b->side_stream[k]);
         if (b->ev_join[k]) hipEventDestroy(b->ev_join[k]);
@@ -956,13 +1063,17 @@ int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* 
     if (!b->hip_ok(hipMemcpyAsync(b->d_io_src, src_host, floats * sizeof(float), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(src)")) return 0;
     if (!mix_device(b, frames, b->d_io_src, b->d_io_dst, b->stream)) return 0;
     if (!b->hip_ok(hipMemcpyAsync(dst_host, b->d_io_dst, floats * sizeof(float), hipMemcpyDeviceToHost, b->stream), "hipMemcpyAsync(dst)")) return 0;
-    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 1 : 0;
+    if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    poll_exact(b);
+    return check_fault(b) ? 1 : 0;
 }
 
 int oalsfx_batch_synchronize(oalsfx_batch* b)
 {
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
-    return b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 1 : 0;
+    if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    poll_exact(b);
+    return check_fault(b) ? 1 : 0;
 }
 
 void* oalsfx_batch_stream(oalsfx_batch* b) { return b->stream; }
@@ -1053,6 +1164,50 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
     if (launches) *launches = n;
     if (total_ms) *total_ms = ms;
     return 1;
+}
+
+int oalsfx_batch_kernel_timing_samples(oalsfx_batch* b, int effect_type, double* out_us, int max_samples)
+{
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+    int key = (effect_type >= 0 && effect_type < OALSFX_REVERB) ? kTimedWaveEffects : effect_type;
+    if (key == OALSFX_REVERB) key = OALSFX_EAX_REVERB;
+    if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset;
+    if (effect_type == 32) key = kTimedMixed;
+    int n = 0;
+    for (auto& t : b->timed) {
+        if (t.type != key) continue;
+        if (out_us && n < max_samples) {
+            if (!b->hip_ok(hipEventSynchronize(t.stop), "hipEventSynchronize")) return -1;
+            float e = 0.0F;
+            if (!b->hip_ok(hipEventElapsedTime(&e, t.start, t.stop), "hipEventElapsedTime")) return -1;
+            out_us[n] = e * 1e3;
+        }
+        ++n;
+    }
+    return n;
+}
+
+int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4])
+{
+    if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    poll_exact(b);
+    if (!sync_params(b, nullptr)) return 0;
+    int light = 0;
+    for (int t = 0; t < OALSFX_REVERB; ++t) light += b->list_count[slot][t];
+    counts[0] = light;
+    counts[1] = b->fast_count[slot];
+    counts[2] = b->slow_count[slot];
+    counts[3] = b->general_count[slot];
+    return 1;
+}
+
+const char* oalsfx_batch_last_reverb_kernel(const oalsfx_batch* b) { return b->last_steady_kernel; }
+
+int oalsfx_device_pci_bus_id(int device_id, char* out, int len)
+{
+    if (!out || len < 16) return 0;
+    return hipDeviceGetPCIBusId(out, len, device_id) == hipSuccess ? 1 : 0;
 }
 
 int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)

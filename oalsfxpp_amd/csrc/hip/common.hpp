@@ -37,7 +37,32 @@ struct KernelCtx {
                                         // channels) and read by the general kernel launched right after on the same list, which
                                         // carries on from there; nullptr otherwise
     unsigned long long* timeline;       // measurement only (OALSFX_DEBUG_TIMELINE): phase time stamps of sampled workgroups, else nullptr
+    // ---- the proven-steady reverb path (reverb.hip, build flag FP) ----
+    unsigned* hot;                      // [instance][slots][hot::SIZE] dwords: what a proven-steady reverb needs to start a buffer, packed (see namespace hot)
+    const unsigned* inst_epoch;         // [instance]: bumped by the host with every parameter upload that touches the instance; stamps the hot records
+    unsigned* exact;                    // [instance][slots]: written by every reverb kernel except the FP builds: 1 when the instance ends the call
+                                        // with its cross-fade finished and every output gain exactly on its target (then "steady" no longer
+                                        // depends on the size of the next call), else 0; the host reads it back lazily
+    unsigned* fault;                    // one counter: instances an FP build found not to be steady after all (a broken host invariant: reported
+                                        // by the next synchronising call, never silently)
+    int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
 };
+
+// The packed per-(instance, slot) start record of the proven-steady reverb kernel: the LDS table image, the filter histories and the
+// wave-uniform odds and ends, 1 KiB, written by the kernel's epilogue for the next call and fetched with one 16-byte load per lane.
+// Valid when its stamp (host epoch of the instance, delay-line position) matches the instance's current ones; rebuilt from the
+// descriptors otherwise.
+namespace hot {
+enum {
+    UT = 0,        // 128 dwords: namespace ut of reverb.hip
+    CHAIN = 128,   // 64 dwords: [line][coop::SIZE] filter histories and feedback coefficients
+    MISC = 192,    // 64 dwords, see below
+    SIZE = 256,
+    // MISC dwords
+    M_EPOCH = 0, M_OFFSET, M_EAX, M_HAS_FILTER, M_AUD_DIR, M_AUD_AUX, M_AUD_OUT, M_LATE_MASK, M_SHORT_MASK, M_MOD_F, M_MOD_INDEX, M_MOD_RANGE,
+    M_MOD_DEPTH, M_MOD_COEFF, M_MOD_ON, M_SEND_MASK, M_COUNT
+};
+}
 
 // How the workgroups of a ring-light grid map to a slot's type-sorted instance list: segment k covers the next `count[k]` list
 // entries, four per workgroup (a segment starts a new workgroup).  A segment whose bit is set in coop_mask holds whole
@@ -72,8 +97,10 @@ constexpr int kWave = 64;
 // samples, which selects the kernel build that can request such groups late; modulated: some listed instance has (or had)
 // a modulated late line, which selects the build that carries the modulation; short_taps: some listed instance has a tap
 // shorter than one tile, which selects the most general build.
-void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
-                          hipStream_t stream);
+// proven: the host has device-confirmed knowledge that every listed instance is steady (mono / stereo, whole tiles): the FP builds.
+// Returns the kernel symbol it launched (template arguments as rocprofv3 prints them), nullptr when the list was empty.
+const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated,
+                                 bool short_taps, bool proven, hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments
@@ -186,6 +213,30 @@ __device__ __forceinline__ void send_history_follow(const KernelCtx& ctx, int in
     const float older = frames >= 2 ? src[static_cast<size_t>(frames - 2) * channels + c] : 0.0F;
     for (int send = 0; send <= ctx.slots; ++send) {
         if (send > 0 && P.aux[send - 1].out_channels == 0) continue;
+        oalsfx_hist_t* h[2] = {&S.lp[send][c], &S.hp[send][c]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (frames >= 2) {
+                h[k]->x[1] = older; h[k]->y[1] = older;
+            } else {
+                h[k]->x[1] = h[k]->x[0]; h[k]->y[1] = h[k]->y[0];
+            }
+            h[k]->x[0] = newest; h[k]->y[0] = newest;
+        }
+    }
+}
+
+// The same for a kernel that already knows which sends are enabled (bit 0 the direct send, bit 1 + s the send to slot s): no
+// parameter loads at the end of the launch.
+__device__ __forceinline__ void send_history_follow_listed(const KernelCtx& ctx, int inst, int c, int channels, int frames, const float* src,
+                                                           unsigned send_mask)
+{
+    if (frames <= 0) return;
+    oalsfx_source_state& S = ctx.source_state[inst];
+    const float newest = src[static_cast<size_t>(frames - 1) * channels + c];
+    const float older = frames >= 2 ? src[static_cast<size_t>(frames - 2) * channels + c] : 0.0F;
+    for (int send = 0; send <= ctx.slots; ++send) {
+        if (!((send_mask >> send) & 1u)) continue;
         oalsfx_hist_t* h[2] = {&S.lp[send][c], &S.hp[send][c]};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {

@@ -235,13 +235,16 @@ __device__ __forceinline__ void lds_barrier()
 // taken from sample L - 1.
 
 // LDS of one workgroup of the cooperative kernel
-template <int CH, int NW>
+template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true>
 struct SteadyShared {
     static constexpr bool MC = CH > 2;
     static constexpr int kMcBase = ut::SIZE + 64 + 8 * kRow; // multichannel tables behind the modulation row and the hand-over rows:
                                                              // GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
-    // mono / stereo: sized for the general path, which non-steady instances fall back to
-    static constexpr int kFloats = MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
+    // FP (proven-steady instances only, nothing falls back inside): the rows, the table, the record's odds and ends, and what the
+    // build's own extras need (modulation row, hand-over rows)
+    static constexpr int kFpMisc = ut::SIZE + (MD ? 64 : 0) + (ST ? 8 * kRow : 0);
+    // mono / stereo otherwise: sized for the general path, which non-steady instances fall back to
+    static constexpr int kFloats = FP ? kGroups * 4 * kRow + kFpMisc + 64 : MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
     alignas(16) float lds_all[NW][kFloats];
     float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     int go_all[NW];
@@ -249,10 +252,17 @@ struct SteadyShared {
 };
 
 // The work of workgroup `group` of the cooperative kernel (its own kernel below; also one half of k_slot_mixed).
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false>
+// FP (with any of plain / HY / MD / ST, whole tiles, mono / stereo): the launch holds only instances the host has *proven* steady
+// (the device reported them exactly settled, DESIGN 4, and nothing has been uploaded for them since).  There is no steady-state
+// test to fail and no general path to fall back to -- neither its registers, its scratch frame nor its 16 KiB of gain-ramp rows --
+// and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
+// loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
+// kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
-                                                    SteadyShared<CH, NW>& sh)
+                                                    SH& sh)
 {
+    static_assert(!FP || (CH <= 2 && !RG), "the proven-steady builds: mono / stereo, whole tiles");
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
     int ts_i = 0;
     auto stamp = [&]() {
@@ -262,7 +272,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp();
     static_assert(CH <= 2 || CH == 8, "mono, stereo, or the multichannel build");
     constexpr bool MC = CH > 2;
-    constexpr int kMcBase = SteadyShared<CH, NW>::kMcBase;
+    constexpr int kMcBase = SH::kMcBase;
     const int nch = MC ? ctx.channels : CH;
     auto& lds_all = sh.lds_all;
     auto& chain_all = sh.chain_all;
@@ -282,7 +292,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     float* utf = lds + kGroups * 4 * kRow;
     unsigned* utu = reinterpret_cast<unsigned*>(utf);
 
-    const int inst = __builtin_amdgcn_readfirstlane(list[valid ? w : 0]);
+    const int inst = (FP && ctx.list_first >= 0) ? ctx.list_first + (valid ? w : 0) : __builtin_amdgcn_readfirstlane(list[valid ? w : 0]);
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
     typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
     ConstSlotParams& SP = *(ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
@@ -291,18 +301,70 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     oalsfx_reverb_state& S = SS.u.reverb;
     GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
 
-    // ---- everything the steady-state path needs from the descriptors, requested in one go: the loads below do not
-    // depend on each other, so the prologue costs one memory round trip after the list entry instead of three
     const int l4 = lane & 3;
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
     const bool q_valid = lane < 8 * CH && q_chan < nch;
+    // what the tile loop and the epilogue need to know about the instance (wave-uniform), from the hot record or the descriptors
+    bool go = false, eax = false, mod_on = false, has_filter = false;
+    unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
+    unsigned short_mask = 0; // ST build: tap groups with a source inside the tile
+    unsigned long long aud_dir = 0, aud_aux = 0, aud_out = 0; // which gains are audible (bit layout as the tables)
+    int offset = 0, v_modidx = 0, v_modrange = 1;
+    float mod_f = 0.0F, mod_depth = 0.0F, mod_coeff = 0.0F;
+    unsigned send_mask = 0; // FP: sends whose filter histories follow the input (bit 0 direct, bit 1 + s the send to slot s)
+    unsigned epoch_now = 0;
+    unsigned* miscu = reinterpret_cast<unsigned*>(utf + (FP ? SH::kFpMisc : 0)); // FP: image of the record's MISC block
+    bool hit = false;
+    if constexpr (FP) {
+        // ---- the hot record: 1 KiB, one 16-byte load per lane, straight into the LDS tables ----
+        const v4u* rec = reinterpret_cast<const v4u*>(ctx.hot + sidx * hot::SIZE);
+        const v4u r = rec[lane];
+        epoch_now = __builtin_amdgcn_readfirstlane(ctx.inst_epoch[inst]);
+        const int offset_now = __builtin_amdgcn_readfirstlane(S.offset);
+        if (lane < 32) *reinterpret_cast<v4u*>(utu + 4 * lane) = r;
+        else if (lane < 48) *reinterpret_cast<v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32)) = r;
+        else *reinterpret_cast<v4u*>(miscu + 4 * (lane - 48)) = r;
+        wave_sync();
+        hit = valid && __builtin_amdgcn_readfirstlane(miscu[hot::M_EPOCH]) == epoch_now &&
+              static_cast<int>(__builtin_amdgcn_readfirstlane(miscu[hot::M_OFFSET])) == offset_now;
+        if (hit) {
+            go = true;
+            offset = offset_now;
+            eax = __builtin_amdgcn_readfirstlane(miscu[hot::M_EAX]) != 0;
+            has_filter = __builtin_amdgcn_readfirstlane(miscu[hot::M_HAS_FILTER]) != 0;
+            aud_dir = __builtin_amdgcn_readfirstlane(miscu[hot::M_AUD_DIR]);
+            aud_aux = __builtin_amdgcn_readfirstlane(miscu[hot::M_AUD_AUX]);
+            aud_out = __builtin_amdgcn_readfirstlane(miscu[hot::M_AUD_OUT]);
+            if (HY) late_mask = __builtin_amdgcn_readfirstlane(miscu[hot::M_LATE_MASK]);
+            if (ST) short_mask = __builtin_amdgcn_readfirstlane(miscu[hot::M_SHORT_MASK]);
+            if (MD) {
+                mod_on = __builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_ON]) != 0;
+                mod_f = __uint_as_float(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_F]));
+                v_modrange = static_cast<int>(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_RANGE]));
+                mod_depth = __uint_as_float(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_DEPTH]));
+                mod_coeff = __uint_as_float(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_COEFF]));
+            }
+            {
+                v_modidx = static_cast<int>(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_INDEX])); // advances in every build
+                if (!MD) v_modrange = static_cast<int>(__builtin_amdgcn_readfirstlane(miscu[hot::M_MOD_RANGE]));
+            }
+            send_mask = __builtin_amdgcn_readfirstlane(miscu[hot::M_SEND_MASK]);
+            if (lane == 0) {
+                go_all[wib] = 1;
+                eax_all[wib] = eax ? 1 : 0;
+            }
+        }
+    }
+    if (!hit) {
+    // ---- everything the steady-state path needs from the descriptors, requested in one go: the loads below do not
+    // depend on each other, so the prologue costs one memory round trip after the list entry instead of three
     const oalsfx_reverb_params& PG = ctx.params[sidx].u.reverb; // per-lane (vector) reads of the parameter block
     const oalsfx_source_params& SG = ctx.source[inst];
     const unsigned v_seen = SS.seen_seq;
     const int v_fade = S.fade_count;
     const float v_modf = S.mod_filter;
     const int v_offset = S.offset;
-    const int v_modidx = S.mod_index, v_modrange = S.mod_range;
+    v_modidx = S.mod_index; v_modrange = S.mod_range;
     const int v_tap = (&S.cur_early_tap[0])[min(lane, 23)];
     const int v_ring_off = PG.ring_off[min(lane >> 2, 4)], v_ring_len = PG.ring_len[min(lane >> 2, 4)];
     const int v_ring_len5 = PG.ring_len[min(lane, 4)];
@@ -318,13 +380,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // send gains: mono / stereo lane = c * 2 + o (direct), c * 4 + k (aux); multichannel lane = c * 8 + o, c * 4 + k
     const float v_gdir = MC ? SG.direct.gains[lane >> 3][lane & 7] : SG.direct.gains[(lane >> 1) & 1][lane & 1];
     const float v_gaux = MC ? SG.aux[slot].gains[(lane >> 2) & 7][lane & 3] : SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
+    mod_depth = P.mod_depth; mod_coeff = P.mod_coeff;
+    mod_f = v_modf;
 
     // ---- is this instance in its steady state for the whole buffer? ----
-    unsigned late_mask = 0;  // hybrid build: tap groups requested in their own tile
-    unsigned short_mask = 0; // ST build: tap groups with a source inside the tile
-    bool go = valid && (RG || (frames & 63) == 0) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
-              (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
-    const bool mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
+    go = valid && (RG || (frames & 63) == 0) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
+         (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
+    mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
     const float g_cur = v_gcur;
     {
         // the last chunk of the buffer has the smallest ramp counter, hence the largest step: no ramp there, no ramp anywhere
@@ -351,27 +413,18 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #pragma unroll
             for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
+        // Exactly settled?  Every output gain on its target (not merely within a step that is too small to ramp: that test
+        // depends on the size of the call) -- what the host needs to know before it may list the instance for an FP build.
+        if (!FP && ctx.exact && valid && go && lane == 0) ctx.exact[sidx] = (__ballot(q_valid && !(g_cur == v_gtgt)) == 0ULL) ? 1u : 0u;
     }
-    const bool eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
+    eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
+    has_filter = (FP || (flags & kFiltered) != 0) && instance_has_send_filter(ctx, inst);
     if (lane == 0) {
         go_all[wib] = go ? 1 : 0;
         eax_all[wib] = (go && eax) ? 1 : 0;
     }
     stamp(); // [1] descriptors read, steady-state test done
 
-    unsigned long long aud_dir = 0, aud_aux = 0, aud_out = 0; // which gains are audible (bit layout as the tables)
-    int offset = 0;
-    // after the send-filter pre-pass an instance with a filter reads its sends' planes, any other instance the raw input
-    const bool filtered = (flags & kFiltered) != 0 && instance_has_send_filter(ctx, inst);
-    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
-    const float* wsrc = src;
-    if (filtered) {
-        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
-        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
-    }
-    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
-    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * nch * OALSFX_MAX_CHUNK : nullptr;
-    const float b2a = 0.288675134595F;
     if (go) {
         // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
         // (flags >> 8) & 32 / 64: timing experiment only (OALSFX_DEBUG_FLAGS), taps rounded to 128 / 256 bytes, results wrong
@@ -419,8 +472,44 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (CH == 1) aud_out = ((aud_out & 1u) | ((aud_out & 2u) << 1) | ((aud_out & 4u) << 2) | ((aud_out & 8u) << 3) | ((aud_out & 16u) << 4) |
                                 ((aud_out & 32u) << 5) | ((aud_out & 64u) << 6) | ((aud_out & 128u) << 7));
         offset = v_offset;
+        if constexpr (FP) {
+            // the parts of the record that do not change from call to call; the epilogue adds the rest
+            typedef const __attribute__((address_space(4))) oalsfx_source_params ConstSourceParams;
+            ConstSourceParams& CS = *(ConstSourceParams*)(uintptr_t)(ctx.source + inst);
+            send_mask = 1u;
+            for (int k = 0; k < ctx.slots; ++k)
+                if (CS.aux[k].out_channels != 0) send_mask |= 2u << k;
+            if (lane == 0) {
+                miscu[hot::M_EAX] = eax ? 1u : 0u;
+                miscu[hot::M_HAS_FILTER] = has_filter ? 1u : 0u;
+                miscu[hot::M_AUD_DIR] = static_cast<unsigned>(aud_dir);
+                miscu[hot::M_AUD_AUX] = static_cast<unsigned>(aud_aux);
+                miscu[hot::M_AUD_OUT] = static_cast<unsigned>(aud_out);
+                miscu[hot::M_LATE_MASK] = late_mask;
+                miscu[hot::M_SHORT_MASK] = short_mask;
+                miscu[hot::M_MOD_RANGE] = static_cast<unsigned>(v_modrange);
+                miscu[hot::M_MOD_DEPTH] = __float_as_uint(mod_depth);
+                miscu[hot::M_MOD_COEFF] = __float_as_uint(mod_coeff);
+                miscu[hot::M_SEND_MASK] = send_mask;
+            }
+        }
         wave_sync(); // this wave's table is complete: the first tile's requests below read it
+    } else if (FP && valid && lane == 0) {
+        atomicAdd(ctx.fault, 1u); // the host listed an instance that is not steady: reported by the next synchronising call
     }
+    } // !hit
+    stamp(); // [1'] tables in place (hot record or descriptors)
+    // after the send-filter pre-pass an instance with a filter reads its sends' planes, any other instance the raw input
+    const bool filtered = (flags & kFiltered) != 0 && has_filter;
+    const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+    const float* wsrc = src;
+    if (filtered) {
+        src = ctx.src + static_cast<size_t>(inst) * ctx.src_stride;
+        wsrc = ctx.wet_src + static_cast<size_t>(inst) * ctx.src_stride;
+    }
+    float* dst = ctx.dst + static_cast<size_t>(inst) * ctx.io_stride;
+    float* mixbuf = ctx.mixbuf ? ctx.mixbuf + static_cast<size_t>(inst) * nch * OALSFX_MAX_CHUNK : nullptr;
+    const float b2a = 0.288675134595F;
 
     // Software pipeline: inputs of tile k+1 are requested before tile k is computed (every tap is >= 2 tiles away).
     v4f n_e = {0, 0, 0, 0}, n_a = n_e, n_el = n_e, n_lt = n_e, n_la = n_e, n_ll = n_e;
@@ -443,13 +532,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // the tile after the ones already prepared; the smoother's chain is strictly sequential, tile after tile
     float* modrow = utf + ut::SIZE;
     auto strow = [&](int k) -> float* { return utf + ut::SIZE + 64 + k * kRow; }; // ST build: 8 hand-over rows
-    float mod_f = v_modf;
     int mod_tiles = 0;
     auto next_mod_delays = [&](int samples_or_64) -> int { // RG: what the tile holds (a ragged call's last tile holds fewer than 64)
         const int samples = RG ? samples_or_64 : 64;
         if (lane == 0) {
             float r = mod_f;
-            const float depth = P.mod_depth, coeff = P.mod_coeff;
+            const float depth = mod_depth, coeff = mod_coeff;
             for (int i = 0; i < samples; ++i) {
                 r = lerpf(r, depth, coeff);
                 modrow[i] = r;
@@ -883,8 +971,27 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             S.offset = offset + frames;
             if (MD && mod_on) S.mod_filter = mod_f;
         }
-        if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
+        if (FP) {
+            if (first && !filtered && lane < nch) send_history_follow_listed(ctx, inst, lane, nch, frames, src, send_mask);
+        } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
     }
+    if constexpr (FP) {
+        // ---- the hot record for the next call: histories and stamp always, the tables when they were rebuilt ----
+        if (go) {
+            if (lane == 0) {
+                miscu[hot::M_EPOCH] = epoch_now;
+                miscu[hot::M_OFFSET] = static_cast<unsigned>(offset + frames);
+                miscu[hot::M_MOD_F] = __float_as_uint(mod_f);
+                miscu[hot::M_MOD_INDEX] = static_cast<unsigned>((static_cast<long long>(v_modidx) + frames) % v_modrange);
+                miscu[hot::M_MOD_ON] = (MD && ((mod_depth != 0.0F) || (mod_f != 0.0F))) ? 1u : 0u;
+            }
+            wave_sync();
+            v4u* rec = reinterpret_cast<v4u*>(ctx.hot + sidx * hot::SIZE);
+            if (lane >= 48) rec[lane] = *reinterpret_cast<const v4u*>(miscu + 4 * (lane - 48));
+            else if (lane >= 32) rec[lane] = *reinterpret_cast<const v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32));
+            else if (!hit) rec[lane] = *reinterpret_cast<const v4u*>(utu + 4 * lane);
+        }
+    } else
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
     if (MC || ctx.progress != nullptr) {
         // the general kernel follows on the same list: tell it how far this instance got
@@ -898,11 +1005,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
-    __shared__ SteadyShared<CH, NW> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1480,6 +1587,12 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         SS.seen_seq = SP.update_seq;
     }
     if (first && !filtered && lane < channels) send_history_follow(ctx, inst, lane, channels, frames, src);
+    // exactly settled (cross-fade over, every output gain on its target)?  The host reads this back before it lists the instance
+    // for a proven-steady build
+    if (ctx.exact) {
+        const bool settled = fade_count >= OALSFX_RV_FADE_SAMPLES && __ballot(q_valid && !(g_cur == g_tgt)) == 0ULL;
+        if (lane == 0) ctx.exact[sidx] = settled ? 1u : 0u;
+    }
 }
 
 
@@ -1538,38 +1651,58 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
     else OALSFX_LAUNCH((k_slot_mixed<2, false>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
 }
 
-// Instances the host believes to be in their steady state: the cooperative tile loop.  An instance that turns out not to
-// be steady (the kernel decides from the device state) falls back to the general path inside the kernel, out of line.
-void launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
-                          hipStream_t stream)
+// Steady instances: the cooperative tile loop.  Believed steady (`proven` false): an instance that turns out not to be (the kernel
+// decides from the device state) falls back to the general path inside the kernel, out of line.  Proven steady: the FP builds.
+// Returns the symbol it launched (as rocprofv3 prints its template arguments), nullptr when there was nothing to launch.
+#define OALSFX_STEADY(...)                                                                                                       \
+    do {                                                                                                                         \
+        OALSFX_LAUNCH((k_reverb_steady_coop<__VA_ARGS__>), grid, block, stream, c, slot, list, count, flags);                    \
+        return "k_reverb_steady_coop<" #__VA_ARGS__ ">";                                                                         \
+    } while (0)
+const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
+                                 bool proven, hipStream_t stream)
 {
-    if (count <= 0) return;
+    if (count <= 0) return nullptr;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
     const bool ragged = (c.frames & 63) != 0; // the call ends in a partial tile: the most general build's ragged variant
+    // template arguments: channels, wavefronts per workgroup, TL, HY, MD, ST, RG, FP
+    if (proven && !ragged && c.channels <= 2) {
+        // the host has proven every listed instance steady: the builds without steady-state test and general path, started from hot records
+        if (c.channels == 1) {
+            if (short_taps) OALSFX_STEADY(1, 4, false, true, true, true, false, true);
+            if (modulated) OALSFX_STEADY(1, 4, false, true, true, false, false, true);
+            if (close_taps) OALSFX_STEADY(1, 4, false, true, false, false, false, true);
+            OALSFX_STEADY(1, 4, false, false, false, false, false, true);
+        }
+        if (short_taps) OALSFX_STEADY(2, 4, false, true, true, true, false, true);
+        if (modulated) OALSFX_STEADY(2, 4, false, true, true, false, false, true);
+        if (c.timeline) OALSFX_STEADY(2, 4, true, false, false, false, false, true);
+        if (close_taps) OALSFX_STEADY(2, 4, false, true, false, false, false, true);
+        OALSFX_STEADY(2, 4, false, false, false, false, false, true);
+    }
     if (c.channels > 2) {
         // multichannel: the most general build only; the caller launches the general kernel on the same list right after
-        if (ragged) OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-        else OALSFX_LAUNCH((k_reverb_steady_coop<8, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-        return;
+        if (ragged) OALSFX_STEADY(8, 4, false, true, true, true, true, false);
+        OALSFX_STEADY(8, 4, false, true, true, true, false, false);
     }
     if (ragged) {
-        if (c.channels == 1) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-        else OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-        return;
+        if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, true, false);
+        OALSFX_STEADY(2, 4, false, true, true, true, true, false);
     }
     if (c.channels == 1) {
-        if (short_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-        else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
-        else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true>), grid, block, stream, c, slot, list, count, flags);
-        else OALSFX_LAUNCH((k_reverb_steady_coop<1, 4>), grid, block, stream, c, slot, list, count, flags);
+        if (short_taps) OALSFX_STEADY(1, 4, false, true, true, true, false, false);
+        if (modulated) OALSFX_STEADY(1, 4, false, true, true, false, false, false);
+        if (close_taps) OALSFX_STEADY(1, 4, false, true, false, false, false, false);
+        OALSFX_STEADY(1, 4, false, false, false, false, false, false);
     }
-    else if (short_taps) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true, true>), grid, block, stream, c, slot, list, count, flags);
-    else if (modulated) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, true>), grid, block, stream, c, slot, list, count, flags);
-    else if (c.timeline) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, true>), grid, block, stream, c, slot, list, count, flags);
-    else if (close_taps) OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true>), grid, block, stream, c, slot, list, count, flags);
-    else OALSFX_LAUNCH((k_reverb_steady_coop<2, 4>), grid, block, stream, c, slot, list, count, flags);
+    if (short_taps) OALSFX_STEADY(2, 4, false, true, true, true, false, false);
+    if (modulated) OALSFX_STEADY(2, 4, false, true, true, false, false, false);
+    if (c.timeline) OALSFX_STEADY(2, 4, true, false, false, false, false, false);
+    if (close_taps) OALSFX_STEADY(2, 4, false, true, false, false, false, false);
+    OALSFX_STEADY(2, 4, false, false, false, false, false, false);
 }
+#undef OALSFX_STEADY
 
 // Everything else: cross-fades, modulation, gain ramps, taps closer than a tile, partial tiles, more than two channels.
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)

@@ -1,6 +1,7 @@
 // oalsfxpp::Api -- the drop-in C++ facade (include/oalsfxpp.h), implemented as a batch of one
 // instance on the current HIP device.  Argument checks, return values and error strings follow the
 // reference facade (reference src/oalsfxpp.cpp:3449-3903); the sample path is the HIP backend.
+#include <cstdlib>
 #include <new>
 
 #include "core.hpp"
@@ -47,7 +48,15 @@ bool Api::initialize(const ChannelFormat channel_format, const int sampling_rate
         error_message_ = err_allocate;
         return false;
     }
+    // The reference's initialize has no notion of a device.  A relinked caller places its instances with OALSFX_DEVICE=<HIP
+    // ordinal> (read at every initialize, so a process may move between calls); default 0.  A value that is not a
+    // valid ordinal fails in oalsfx_batch_create with its message.
     int device = 0;
+    if (const char* env = std::getenv("OALSFX_DEVICE")) {
+        char* end = nullptr;
+        const long v = std::strtol(env, &end, 10);
+        device = (end != env && *end == 0 && v >= 0 && v < (1 << 16)) ? static_cast<int>(v) : -1;
+    }
     pimpl_->batch = oalsfx_batch_create(1, static_cast<int>(channel_format), sampling_rate, effect_count, device);
     if (!pimpl_->batch) {
         // the message of a failed create lives in thread-local storage of the library; keep a static

@@ -42,6 +42,10 @@ SIGNATURES = {
     "oalsfx_batch_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "oalsfx_batch_kernel_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "oalsfx_batch_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "oalsfx_batch_kernel_timing_samples": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "oalsfx_batch_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
+    "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
     "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),

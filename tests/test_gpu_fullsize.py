@@ -1,0 +1,165 @@
+"""GPU parity at the sizes and through the vectors the smaller tests leave out.
+
+  * BASELINE configs[4]'s per-GPU shard: 32 768 EAX reverbs on one GPU (one 28.75 GiB pool chunk, eight residency rounds of
+    workgroups, 64-bit slab strides), instances from the first, middle and last regions of the pool against the oracle;
+  * BASELINE configs[2] at full size (4096 instances x 4 slots);
+  * every golden case recorded from the compiled reference (tests/golden/) through the HIP path: outputs, the host update
+    path's derived parameters as computed on *this* box, final effect state and delay rings;
+  * sampling rates above 192 kHz up to the reference's maximum of 8 MHz (reference src/oalsfxpp.cpp:51-52).
+"""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from generate import run_case  # noqa: E402
+from harness import OracleShadow, make_effect, preset_effect, same_bits  # noqa: E402
+from oalsfxpp_amd import desc  # noqa: E402
+from oalsfxpp_amd.api import Batch  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from test_oracle_golden import CASES, GOLD, ulp_close  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+E = make_effect
+
+
+def replicas_and_sample(n, slots, program, sample, buffers, frames=256):
+    """Every instance hears the same input except the sampled ones, which hear their own and are followed by the oracle:
+    the replicas must stay bit-identical to each other, the sample must match the oracle (outputs, state, delay rings)."""
+    with Batch(n, desc.FMT_STEREO, 48000, slots) as b:
+        program(b)
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in sample}
+        rest = np.setdiff1d(np.arange(n), sample)
+        x = np.empty((n, frames, 2), dtype=np.float32)
+        for k in range(buffers):
+            x[:] = orc.synth(7, k, frames * 2).reshape(frames, 2)
+            for i in sample:
+                x[i] = orc.synth(1000 + i, k, frames * 2).reshape(frames, 2)
+            y = b.mix(x)
+            for i in sample:
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                assert ok, f"instance {i} buffer {k}: {nbad} samples differ"
+            r = y[rest]
+            assert (r.view(np.uint32) == r[0].view(np.uint32)).all(), f"buffer {k}: replicas diverged"
+        for i in sample:
+            d = shadows[i].compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+def test_config5_shard_32768_eax_reverbs():
+    """One GPU's share of BASELINE configs[4] (262 144 instances over 8 GPUs): instance independence
+    (reference src/oalsfxpp.cpp:2984-3037) at the size where the ring pool is a single 28.75 GiB allocation."""
+    n = 32768
+    sample = [0, 1, 2, 3, 5, 4095, 4096, 16383, 16384, 16385, 20000, 32764, 32765, 32766, 32767]
+    replicas_and_sample(n, 1, lambda b: b.set_effect_type(0, desc.EAX_REVERB), sample, buffers=7)
+
+
+def test_config3_full_size_four_slots():
+    """BASELINE configs[2] at full size: 4096 instances x (chorus, flanger, echo, EAX reverb), parallel-sum semantics."""
+    def program(b):
+        for slot, t in enumerate((desc.CHORUS, desc.FLANGER, desc.ECHO, desc.EAX_REVERB)):
+            b.set_effect_type(slot, t)
+    replicas_and_sample(4096, 4, program, [0, 1, 2, 3, 255, 2047, 2048, 4092, 4093, 4094, 4095], buffers=7)
+
+
+class BatchAsApi:
+    """The call surface tests/golden/generate.run_case drives, on a two-instance Batch (both instances get every call)."""
+
+    def __init__(self, case):
+        self.b = Batch(2, case["fmt"], case["rate"], case["slots"])
+
+    def set_effect(self, slot, effect):
+        self.b.set_effect(slot, effect)
+
+    def set_send_props(self, slot, gain, gain_hf, gain_lf):
+        self.b.set_send_props(slot, gain, gain_hf, gain_lf)
+
+    def apply_changes(self):
+        self.b.apply_changes()
+
+    def mix(self, x):
+        y = self.b.mix(np.stack([x, x]))
+        assert y[0].tobytes() == y[1].tobytes(), "two instances with the same calls and input differ"
+        return y[0]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_case_on_the_device(name):
+    """The reference's own outputs (recorded from the compiled reference, tests/golden/generate.py) against the HIP path,
+    with the derived parameters the product's host update path computes on this machine.  Integers must be equal and floats
+    within 2 ulp of the reference's; where all of them are bit-identical (same libm results) the outputs, the final effect
+    state and the delay rings must be bit-identical too, otherwise the outputs are held to BASELINE's 1e-5 of peak."""
+    case = CASES[name]
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    api = BatchAsApi(case)
+    try:
+        out = run_case(api, case, lambda a, s, e: a.set_effect(s, e))
+        b = api.b
+        moved = []
+        for s in range(case["slots"]):
+            p, _ = b.read_slot(0, s)
+            gp = desc.SlotParams.from_buffer_copy(gold[f"params{s}"].tobytes())
+            assert p.type == gp.type
+            if p.type in desc.PARAMS_MEMBER:
+                m = desc.PARAMS_MEMBER[p.type]
+                ctype = type(getattr(p.u, m))
+                bad = ulp_close(bytes(getattr(p.u, m)), bytes(getattr(gp.u, m)), ctype)
+                assert not bad, "derived parameters: " + "; ".join(bad[:5])
+                moved += ulp_close(bytes(getattr(p.u, m)), bytes(getattr(gp.u, m)), ctype, max_ulp=0)
+        sp, _ = b.read_source(0)
+        bad = ulp_close(bytes(sp), gold["source"].tobytes(), desc.SourceParams)
+        assert not bad, "send parameters: " + "; ".join(bad[:5])
+        moved += ulp_close(bytes(sp), gold["source"].tobytes(), desc.SourceParams, max_ulp=0)
+        if moved:
+            # this host's libm rounds an update-path coefficient differently from the build container's: the process path
+            # cannot be bit-identical to the recording any more; hold it to the task's tolerance and say so
+            print(f"{name}: {len(moved)} derived coefficient(s) differ in the last bits on this host: " + "; ".join(moved[:3]))
+            peak = max(1.0, float(np.nanmax(np.abs(gold["out"]))))
+            err = float(np.nanmax(np.abs(out - gold["out"])))
+            assert err <= 1e-5 * peak, f"max |diff| {err:.3g} against a peak of {peak:.3g}"
+            return
+        ok, nbad = same_bits(out, gold["out"])
+        assert ok, f"{nbad} of {out.size} output samples differ from the reference"
+        for s in range(case["slots"]):
+            p, st = b.read_slot(0, s)
+            if p.type in desc.STATE_MEMBER:
+                m = desc.STATE_MEMBER[p.type]
+                gs = desc.SlotState.from_buffer_copy(gold[f"state{s}"].tobytes())
+                ok, _ = same_bits(np.frombuffer(bytes(getattr(st.u, m)), dtype=np.float32), np.frombuffer(bytes(getattr(gs.u, m)), dtype=np.float32))
+                assert ok, f"slot {s}: final effect state differs from the reference"
+            assert zlib.crc32(b.read_ring(0, s).tobytes()) == int(gold[f"ring{s}"][0]), f"slot {s}: final delay rings differ from the reference"
+    finally:
+        api.b.close()
+
+
+@pytest.mark.parametrize("rate", [384000, 1000000, 8000000])
+def test_rates_above_192_khz(rate):
+    """The reference only checks the lower bound of the sampling rate (src/oalsfxpp.cpp:2861) and names 8 MHz as the
+    maximum (:51-52): every ring is that much longer, every tap that much further away."""
+    setups = [(0, E(desc.EAX_REVERB)), (0, E(desc.ECHO)), (0, E(desc.CHORUS)), (0, E(desc.EQUALIZER)), (0, preset_effect(112)),
+              (0, E(desc.FLANGER, waveform=0, rate=7.0, depth=1.0))]
+    if rate > 1000000:
+        setups = setups[:4]
+    n = len(setups)
+    with Batch(n, desc.FMT_STEREO, rate, 1) as b:
+        for i, (slot, e) in enumerate(setups):
+            b.set_effect(slot, e, first=i, count=1)
+        b.apply_changes()
+        shadows = [OracleShadow(b, i) for i in range(n)]
+        for k, frames in enumerate([256, 256, 256, 100, 256, 2048, 256]):
+            x = np.stack([orc.synth(50 + i, k, frames * 2).reshape(frames, 2) for i in range(n)])
+            y = b.mix(x)
+            for i in range(n):
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                assert ok, f"{rate} Hz, instance {i}, call {k}: {nbad} samples differ"
+        for i in range(n):
+            d = shadows[i].compare_state()
+            assert not d, f"{rate} Hz, instance {i}: " + "; ".join(d[:4])

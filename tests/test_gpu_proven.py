@@ -1,0 +1,173 @@
+"""GPU parity of the proven-steady reverb path (build flag FP): the kernels without steady-state test and general
+fallback, started from hot records.
+
+What has to hold: an instance only gets there after the device reported it exactly settled; a parameter or send change takes
+it off again until the device confirms; a hot record is used only while its stamp matches (another kernel advancing the
+instance, e.g. for a ragged call, invalidates it); and through all of that outputs, state and delay lines stay bit-identical to
+the oracle."""
+import numpy as np
+import pytest
+
+from harness import OracleShadow, make_effect, preset_effect, same_bits
+from oalsfxpp_amd import desc
+from oalsfxpp_amd.api import Batch
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+E = make_effect
+
+
+class Follow:
+    """A batch with an oracle shadow on every instance."""
+
+    def __init__(self, fmt, rate, slots, setups):
+        self.b = Batch(len(setups), fmt, rate, slots)
+        for i, eff in enumerate(setups):
+            for slot, e in eff:
+                self.b.set_effect(slot, e, first=i, count=1)
+        self.b.apply_changes()
+        self.shadows = [OracleShadow(self.b, i) for i in range(len(setups))]
+        self.k = 0
+
+    def apply(self):
+        self.b.apply_changes()
+        for s in self.shadows:
+            s.sync()
+
+    def mix(self, frames):
+        b = self.b
+        x = np.stack([orc.synth(300 + i, self.k, frames * b.channels).reshape(frames, b.channels) for i in range(b.n)])
+        y = b.mix(x)
+        for i, s in enumerate(self.shadows):
+            ok, nbad = same_bits(y[i], s.mix(x[i]))
+            assert ok, f"instance {i} call {self.k} ({frames} frames): {nbad} samples differ"
+        self.k += 1
+
+    def check_state(self):
+        for i, s in enumerate(self.shadows):
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+    def close(self):
+        self.b.close()
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_promotion_demotion_and_record_invalidation(fmt):
+    n = 9
+    f = Follow(fmt, 48000, 1, [[(0, E(desc.EAX_REVERB if i % 2 == 0 else desc.REVERB))] for i in range(n)])
+    try:
+        b = f.b
+        assert b.plan(0) == (0, 0, 0, n)                 # fresh instances: cross-fading, general kernel
+        f.mix(256)
+        assert b.plan(0) == (0, n, 0, 0)                 # the device reported them settled, the host-pointer call waited: proven
+        f.mix(256)                                        # records built from the descriptors
+        assert "true>" in b.last_reverb_kernel and b.last_reverb_kernel.endswith("false, true>")
+        f.mix(256); f.mix(64); f.mix(2048); f.mix(4096)  # record hits, every whole-tile call size, several chunks per call
+        # a ragged call runs on the believing build and moves the delay-line positions: the records' stamps no longer match
+        f.mix(100)
+        assert "false, true>" not in b.last_reverb_kernel
+        f.mix(256); f.mix(256)
+        assert b.last_reverb_kernel.endswith("false, true>")
+        # a send change alone: off the proven list until the device confirms (it stays steady)
+        b.set_send_props(-1, 0.7, 1.0, 1.0, first=2, count=1)
+        b.set_send_props(0, 0.5, 1.0, 1.0, first=3, count=1)
+        f.apply()
+        assert b.plan(0) == (0, n - 2, 2, 0)
+        f.mix(256)
+        assert b.plan(0) == (0, n, 0, 0)
+        f.mix(256)
+        # a property change: general kernel while it cross-fades, then back
+        b.set_effect(0, preset_effect(8), first=4, count=1)
+        b.set_effect(0, preset_effect(26, desc.REVERB), first=5, count=1)
+        f.apply()
+        # (instance 3's auxiliary send differs from its never-written deferred copy for good: the reference recomputes such a source
+        # on every apply, reference src/oalsfxpp.cpp:3772-3780, so every apply takes it off the proven list for one call)
+        assert b.plan(0) == (0, n - 3, 1, 2)
+        f.mix(64)
+        assert b.plan(0) == (0, n - 2, 0, 2)              # 64 frames: the 128-frame cross-fade is not over
+        f.mix(64); f.mix(256); f.mix(256)
+        assert b.plan(0)[3] == 0 and b.plan(0)[1] >= n - 2
+        # a type change and back
+        b.set_effect_type(0, desc.ECHO, first=0, count=1)
+        f.apply()
+        f.mix(256)
+        b.set_effect_type(0, desc.EAX_REVERB, first=0, count=1)
+        f.apply()
+        for _ in range(4):
+            f.mix(256)
+        assert b.plan(0)[1] == n
+        f.check_state()
+    finally:
+        f.close()
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_every_proven_build(fmt):
+    """Plain, close-tap (room: 96-sample taps), modulated (drugged, dizzy) and short-tap (bathroom: 59) presets, each kind in a
+    batch of its own so that the launch picks that build, long enough for many record hits."""
+    kinds = {"plain": [0, 4, 12], "close": [2, 0], "modulated": [23, 24, 0], "short": [3, 25, 23, 2, 0]}
+    for kind, presets in kinds.items():
+        f = Follow(fmt, 48000, 1, [[(0, preset_effect(p, desc.EAX_REVERB if j % 2 == 0 else desc.REVERB))] for j, p in enumerate(presets * 2)])
+        try:
+            for frames in (256, 256, 256, 256, 64, 1024, 256, 256):
+                f.mix(frames)
+            plan = f.b.plan(0)
+            assert plan[1] > 0, f"{kind}: nothing was proven steady: {plan}"
+            assert f.b.last_reverb_kernel.endswith("true>"), (kind, f.b.last_reverb_kernel)
+            f.check_state()
+        finally:
+            f.close()
+
+
+def test_proven_reverbs_beside_other_slots_and_filters():
+    """Multi-slot batches: a reverb slot behind a fused run of ring-light slots, with the send-filter pre-pass switched on and off;
+    the proven build reads mixbuf and the filtered planes like the believing one."""
+    chain = [(0, E(desc.CHORUS)), (1, E(desc.ECHO)), (2, E(desc.EAX_REVERB))]
+    f = Follow(desc.FMT_STEREO, 48000, 3, [chain] * 6)
+    try:
+        b = f.b
+        for _ in range(3):
+            f.mix(256)
+        assert b.plan(2)[1] == 6
+        b.set_send_props(-1, 0.9, 0.5, 1.0, first=1, count=2)
+        b.set_send_props(2, 1.0, 0.4, 0.6, first=2, count=2)
+        f.apply()
+        for _ in range(3):
+            f.mix(256)
+        assert b.plan(2)[1] == 6
+        b.set_send_props(-1, 1.0, 1.0, 1.0, first=1, count=2)
+        b.set_send_props(2, 1.0, 1.0, 1.0, first=2, count=2)
+        f.apply()
+        for _ in range(3):
+            f.mix(256)
+        f.check_state()
+    finally:
+        f.close()
+
+
+def test_proven_path_without_waiting_for_the_stream():
+    """Device-resident buffers, no synchronising call between the mixes: the read-back of the settled flags arrives whenever it
+    arrives, the host promotes then; results are the same whichever kernel took an instance."""
+    import torch
+    n, frames = 64, 256
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect(i % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 17, 63)}
+        xs = [np.stack([orc.synth(900 + i, k, frames * 2).reshape(frames, 2) for i in range(n)]) for k in range(40)]
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = [torch.empty_like(d) for d in dx]
+        torch.cuda.synchronize()
+        for k in range(40):
+            b.mix_device(frames, dx[k].data_ptr(), dy[k].data_ptr())
+        b.synchronize()
+        assert b.plan(0)[3] == 0
+        for k in range(40):
+            y = dy[k].cpu().numpy()
+            for i, s in shadows.items():
+                ok, nbad = same_bits(y[i], s.mix(xs[k][i]))
+                assert ok, f"instance {i} buffer {k}: {nbad} samples differ"
+        for i, s in shadows.items():
+            assert not s.compare_state(), f"instance {i}: state differs"
