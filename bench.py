@@ -47,6 +47,8 @@ WORKLOADS = {
                "256-frame buffers (BASELINE.json configs[2])",
     "config4": "{n} instances per GPU, 1 slot, effect type 1 + i%11, every property uniform in its range (seed = instance), "
                "stereo, 48 kHz, 256-frame buffers (BASELINE.json configs[3])",
+    "config5": "{n} independent EAX-reverb instances per GPU (one GPU's share of BASELINE.json configs[4]: 262144 over 8 GPUs), stereo, "
+               "48 kHz, 256-frame buffers, 1 slot, default properties",
 }
 
 
@@ -134,21 +136,121 @@ def cpu_baseline(target_seconds=12.0):
     }
 
 
+def percentile(sorted_values, q):
+    if not sorted_values:
+        return 0.0
+    k = (len(sorted_values) - 1) * q
+    lo = int(k)
+    hi = min(lo + 1, len(sorted_values) - 1)
+    return sorted_values[lo] + (sorted_values[hi] - sorted_values[lo]) * (k - lo)
+
+
+ROOFLINE_WARMUP = 64       # the fixed internal region the roofline object is measured on, whatever --steps / --warmup say
+ROOFLINE_LAUNCHES = 128
+
+
+def device_record(rank, ordinal):
+    """Which GPU this rank runs on: HIP ordinal inside the process's visibility mask, PCI bus id, marketing name."""
+    import ctypes as C
+    import torch
+    from oalsfxpp_amd import lib
+    buf = C.create_string_buffer(64)
+    so = lib.load()
+    pci = buf.value.decode() if hasattr(so, "oalsfx_device_pci_bus_id") and so.oalsfx_device_pci_bus_id(ordinal, buf, 64) else None
+    return {"rank": rank, "ordinal": ordinal, "pci_bus_id": pci or buf.value.decode() or None, "name": torch.cuda.get_device_name(ordinal),
+            "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+
+
+def timed_region(batch, src, dst, n_in, first_step, steps, sharding, backend):
+    """`steps` mix calls bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time."""
+    import torch
+    batch.synchronize()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        batch.mix_device(FRAMES, src[(first_step + k) % n_in].data_ptr(), dst.data_ptr())
+    batch.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sharding.barrier()
+    torch.cuda.synchronize()
+    return sharding.max_over_ranks(elapsed, device="cuda" if backend == "nccl" else "cpu")
+
+
+def resident_inputs(batch, n, rank, n_in=8):
+    """Inputs resident in HBM: a ring of pre-generated buffers, one output buffer."""
+    import torch
+    floats = n * FRAMES * CHANNELS
+    src = [torch.empty(floats, dtype=torch.float32, device="cuda") for _ in range(n_in)]
+    dst = torch.empty(floats, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for k, s in enumerate(src):
+        batch.fill_synthetic(FRAMES, k + 1000 * rank, s.data_ptr())
+    batch.synchronize()
+    return src, dst
+
+
+def roofline_region(batch, src, dst, n_in, first_step, bytes_per_launch):
+    """The dominant kernel alone, on a region of fixed length: ROOFLINE_WARMUP untimed launches, then ROOFLINE_LAUNCHES launches
+    each bracketed by HIP events on the launch stream; the empty-pair reading is taken off every sample; frac uses the median."""
+    from oalsfxpp_amd import desc
+    for k in range(ROOFLINE_WARMUP):
+        batch.mix_device(FRAMES, src[(first_step + k) % n_in].data_ptr(), dst.data_ptr())
+    batch.synchronize()
+    batch.kernel_timing(1)
+    for k in range(ROOFLINE_LAUNCHES):
+        batch.mix_device(FRAMES, src[(first_step + ROOFLINE_WARMUP + k) % n_in].data_ptr(), dst.data_ptr())
+    batch.synchronize()
+    raw = sorted(batch.kernel_timing_samples(desc.EAX_REVERB))
+    general = batch.kernel_timing_read(desc.REVERB + 16)[0]
+    batch.kernel_timing(0)
+    bracket_us = batch.event_overhead(200)
+    us = [max(x - bracket_us, 0.0) for x in raw]
+    med = percentile(us, 0.5)
+    achieved = bytes_per_launch / (med * 1e-6) / 1e9 if med > 0 else 0.0
+    return {
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "kernel": batch.last_reverb_kernel,
+        "kernel_us": round(med, 2),
+        "kernel_us_min": round(us[0], 2) if us else None,
+        "kernel_us_p10": round(percentile(us, 0.1), 2),
+        "kernel_us_p90": round(percentile(us, 0.9), 2),
+        "kernel_us_max": round(us[-1], 2) if us else None,
+        "kernel_us_mean": round(sum(us) / max(len(us), 1), 2),
+        "kernel_us_event_pair": round(percentile(raw, 0.5), 2),
+        "event_pair_empty_us": round(bracket_us, 2),
+        "launches_timed": len(us),
+        "region": f"{ROOFLINE_WARMUP} untimed + {ROOFLINE_LAUNCHES} event-timed launches after the CLI-timed region; frac from the median",
+        "general_kernel_launches_in_region": general,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default 4096; 8192 for config4)")
+    ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default 4096; 8192 for config4, 32768 for config5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiment: no HIP events around the launches (roofline fields then use the step time)")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
     ap.add_argument("--preset", type=int, default=-1, help="experiment: every instance uses EFX preset N")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4"],
-                    help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain) or configs[3] "
-                         "(11 effect types, randomised properties; 8192 instances unless --instances is given)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
+                    help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain), configs[3] (11 effect types, "
+                         "randomised properties; 8192 instances unless --instances is given) or one GPU's share of configs[4] "
+                         "(32768 EAX reverbs per GPU)")
+    ap.add_argument("--config5", action="store_true", help="also time one GPU's share of configs[4] (32768 instances per GPU) and report it as "
+                                                           "the `config5` object; always on when --gpus > 1")
     ap.add_argument("--host-io", type=int, default=10, metavar="K",
-                    help="after the timed region, also time K steps through oalsfx_batch_mix (host buffers, PCIe both ways)")
+                    help="after the timed region, also time K steps through the host-pointer entry points (PCIe both ways)")
     args = ap.parse_args()
 
     import torch
@@ -173,9 +275,15 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    mine = device_record(rank, local_rank)
+    devices = [mine]
+    if distributed:
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
 
-    n = args.instances or (8192 if args.workload == "config4" else 4096)
-    workload = "config2-presets" if args.preset_mix else args.workload
+    config5_main = args.workload == "config5"
+    n = args.instances or {"config4": 8192, "config5": 32768}.get(args.workload, 4096)
+    workload = "config2-presets" if args.preset_mix else ("config2" if config5_main else args.workload)
     batch = Batch(n, desc.FMT_STEREO, 48000, workloads.effect_count(workload), device_id=local_rank)
     if args.preset >= 0:
         e = lib.effect_defaults(desc.EAX_REVERB)
@@ -187,38 +295,16 @@ def main():
     else:
         workloads.setup(batch, workload, first_instance=rank * n)
 
-    # inputs resident in HBM: a ring of pre-generated buffers, one output buffer
     n_in = 8
-    floats = n * FRAMES * CHANNELS
-    src = [torch.empty(floats, dtype=torch.float32, device="cuda") for _ in range(n_in)]
-    dst = torch.empty(floats, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    for k, s in enumerate(src):
-        batch.fill_synthetic(FRAMES, k + 1000 * rank, s.data_ptr())
-    batch.synchronize()
-
-    def step(k):
-        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
-
+    src, dst = resident_inputs(batch, n, rank, n_in)
     for k in range(args.warmup):
-        step(k)
-    batch.synchronize()
-    torch.cuda.synchronize()
-    sharding.barrier()
-    torch.cuda.synchronize()
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
 
     # every 8th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
     # be part of `value`
-    batch.kernel_timing(0 if args.no_kernel_timing else TIMED_EVERY)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
     batch.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sharding.barrier()
-    torch.cuda.synchronize()
-    elapsed = sharding.max_over_ranks(elapsed, device="cuda" if backend == "nccl" else "cpu")
+    batch.kernel_timing(0 if args.no_kernel_timing else TIMED_EVERY)
+    elapsed = timed_region(batch, src, dst, n_in, args.warmup, args.steps, sharding, backend)
 
     # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
     kernels = {}
@@ -229,6 +315,7 @@ def main():
         l, ms = batch.kernel_timing_read(t)
         if l:
             kernels[name] = {"launches": l, "avg_us": round(ms / l * 1e3, 2)}
+    batch.kernel_timing(False)
     frames_per_launch = n * FRAMES
     if workload == "config3":
         bytes_per_step = workloads.CONFIG3_BYTES_PER_FRAME * frames_per_launch
@@ -236,22 +323,20 @@ def main():
         bytes_per_step = sum(workloads.BYTES_PER_FRAME[workloads.config4_type(rank * n + i)] for i in range(n)) * FRAMES
     else:
         bytes_per_step = BYTES_PER_FRAME * frames_per_launch
+    plan = batch.plan(workloads.effect_count(workload) - 1)
     if workload == "config2" and not args.no_kernel_timing:
-        # the headline: the dominant kernel alone
-        launches, kernel_ms = batch.kernel_timing_read(desc.EAX_REVERB)
+        # the headline: the dominant kernel alone, on its own fixed region
+        roofline = roofline_region(batch, src, dst, n_in, args.warmup + args.steps, bytes_per_step)
     else:
         # several kernels share a step, some of them side by side on forked streams: the step's algorithmic bytes
         # against the step time itself
-        launches = args.steps
-        kernel_ms = elapsed * 1e3
-    batch.kernel_timing(False)
-    # an event pair reads about 4.4 us with nothing between the two events: measured on the same stream and taken off, which
-    # brings the figure within 2 % of rocprofv3's kernel trace of the same run (the raw figure stays in the line)
-    bracket_us = batch.event_overhead(200) if (workload == "config2" and not args.no_kernel_timing) else 0.0
-    raw_kernel_us = kernel_ms / max(launches, 1) * 1e3
-    kernel_ms = max(kernel_ms - launches * bracket_us / 1e3, 0.0)
-    avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-    achieved_gbs = bytes_per_step / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        step_s = elapsed / args.steps
+        achieved = bytes_per_step / step_s / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "kernel": "all effect kernels of a step (algorithmic bytes of the step / step time)",
+                    "kernel_us": round(step_s * 1e6, 2), "launches_timed": args.steps, "algorithmic_bytes_per_launch": bytes_per_step}
+    roofline["launch_plan_last_slot"] = {"ring_light": plan[0], "reverbs_proven_steady": plan[1], "reverbs_believed_steady": plan[2],
+                                         "reverbs_general": plan[3]}
 
     total_frames = world * n * FRAMES * args.steps
     result = {
@@ -268,63 +353,118 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": WORKLOADS[workload].format(n=n),
+            "workload": (WORKLOADS["config5"] if config5_main else WORKLOADS[workload]).format(n=n),
             "instances_per_gpu": n,
             "frames_per_buffer": FRAMES,
             "parallelism": f"batch-split x{world}, no collectives",
+            "devices": devices,
         },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved_gbs, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-            "traffic": None,
-            "kernel": {"config2": "k_reverb_steady_coop<2,4>", "config2-presets": "k_reverb_steady_coop<2,4> + k_reverb<2>"}.get(
-                workload, "all effect kernels of a step"),
-            "kernel_us": round(avg_kernel_s * 1e6, 2),
-            "kernel_us_event_pair": round(raw_kernel_us, 2),
-            "event_pair_empty_us": round(bracket_us, 2),
-            "launches_timed": launches,
-            "algorithmic_bytes_per_launch": bytes_per_step,
-        },
+        "roofline": roofline,
         "kernels": kernels,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(traffic_file) and workload == "config2" and n == 4096:
+    if os.path.exists(traffic_file) and workload == "config2" and n == 4096 and not args.no_kernel_timing:
         with open(traffic_file) as f:
             t = json.load(f)
+        if os.environ.get("OALSFX_TRAFFIC_REFRESH"):
+            t = {}  # the counter passes that produce the next traffic.json run this very script (scripts/profile_pmc.sh)
+        elif t.get("kernel") != roofline["kernel"]:
+            # the committed counter run belongs to another kernel: say so instead of attaching its bytes to this one
+            raise SystemExit(f"profiles/traffic.json was measured on {t.get('kernel')!r} but this run launched {roofline['kernel']!r}: "
+                             "refresh it from a --pmc pass of this build (scripts/profile_pmc.sh)")
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         result["roofline"]["traffic_source"] = t.get("source")
 
+    if os.environ.get("OALSFX_DUMP_OUTPUT"):
+        # rehearsal hook (tests/test_gpu_async_and_ranks.py): this rank's last output buffer, to compare with a single-process run
+        import numpy as np
+        np.save(os.environ["OALSFX_DUMP_OUTPUT"], dst.cpu().numpy())
     if args.host_io > 0 and world == 1:
-        # PCIe-inclusive rate (never `value`; single-GPU runs only): pinned host buffers through oalsfx_batch_mix, synchronous per step
-        hsrc = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).uniform_(-1, 1).pin_memory()
-        hdst = torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).pin_memory()
-        import ctypes as C
-        fp = C.POINTER(C.c_float)
-        so = lib.load()
-        call = lambda: so.oalsfx_batch_mix(batch._h, FRAMES, C.cast(hsrc.data_ptr(), fp), C.cast(hdst.data_ptr(), fp))
-        for _ in range(3):
-            assert call()
-        t0 = time.perf_counter()
-        for _ in range(args.host_io):
-            assert call()
-        dt = time.perf_counter() - t0
-        result["host_io"] = {"value": round(n * FRAMES * args.host_io / dt / 1e6, 3), "unit": "Msamples/s",
-                             "ms_per_step": round(dt / args.host_io * 1e3, 4), "steps": args.host_io,
-                             "note": "pinned host src/dst, H2D + kernels + D2H + sync per step, not overlapped"}
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
-    elif rank == 0:
-        result["cpu_baseline"] = None
-
+        result["host_io"] = host_io_leg(batch, n, args.host_io)
     batch.close()
+    del src, dst
+    torch.cuda.empty_cache()
+
+    if (args.config5 or distributed) and not config5_main:
+        result["config5"] = config5_leg(rank, world, local_rank, min(args.steps, 100), sharding, backend)
+
     if distributed:
         dist.destroy_process_group()
     if rank == 0:
+        # the CPU path in the same run (north_star), on rank 0's host cores, after the ranks have parted
+        result["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         print(json.dumps(result), flush=True)
+
+
+def host_io_leg(batch, n, steps):
+    """PCIe-inclusive rates (never `value`; single-GPU runs only), pinned host buffers: every call synchronous
+    (oalsfx_batch_mix), and pipelined across successive calls (oalsfx_batch_mix_async / oalsfx_batch_wait) where the library has it."""
+    import ctypes as C
+    import torch
+    from oalsfxpp_amd import lib
+    fp = C.POINTER(C.c_float)
+    so = lib.load()
+    depth = 3
+    hsrc = [torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).uniform_(-1, 1).pin_memory() for _ in range(depth)]
+    hdst = [torch.empty(n, FRAMES, CHANNELS, dtype=torch.float32).pin_memory() for _ in range(depth)]
+    call = lambda k: so.oalsfx_batch_mix(batch._h, FRAMES, C.cast(hsrc[k % depth].data_ptr(), fp), C.cast(hdst[k % depth].data_ptr(), fp))
+    for k in range(3):
+        assert call(k)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        assert call(k)
+    dt = time.perf_counter() - t0
+    out = {"value": round(n * FRAMES * steps / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "note": "pinned host src/dst, H2D + kernels + D2H + sync per step, not overlapped"}
+    if hasattr(so, "oalsfx_batch_mix_async"):
+        acall = lambda k: so.oalsfx_batch_mix_async(batch._h, FRAMES, C.cast(hsrc[k % depth].data_ptr(), fp), C.cast(hdst[k % depth].data_ptr(), fp))
+        psteps = max(steps, 30)
+        for k in range(depth):
+            assert acall(k)
+        assert so.oalsfx_batch_wait(batch._h)
+        t0 = time.perf_counter()
+        for k in range(psteps):
+            assert acall(k)     # waits by itself for the call that last used this staging slot
+        assert so.oalsfx_batch_wait(batch._h)
+        dt = time.perf_counter() - t0
+        out["pipelined"] = {"value": round(n * FRAMES * psteps / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt / psteps * 1e3, 4),
+                            "steps": psteps, "note": "oalsfx_batch_mix_async x K then oalsfx_batch_wait: H2D of call k+1, kernels of call k and "
+                                                     "D2H of call k-1 overlap on three streams"}
+    return out
+
+
+def config5_leg(rank, world, local_rank, steps, sharding, backend):
+    """One GPU's share of BASELINE.json configs[4] (262144 EAX reverbs over 8 GPUs = 32768 per GPU, 28.75 GiB of delay lines each),
+    timed like the main region."""
+    from oalsfxpp_amd import desc, workloads
+    from oalsfxpp_amd.api import Batch
+    n = 32768
+    batch = Batch(n, desc.FMT_STEREO, 48000, 1, device_id=local_rank)
+    workloads.setup(batch, "config2", first_instance=rank * n)
+    n_in = 4
+    src, dst = resident_inputs(batch, n, rank, n_in)
+    for k in range(16):
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+    batch.synchronize()
+    for k in range(16):
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+    batch.kernel_timing(TIMED_EVERY)
+    elapsed = timed_region(batch, src, dst, n_in, 32, steps, sharding, backend)
+    launches, ms = batch.kernel_timing_read(desc.EAX_REVERB)
+    batch.kernel_timing(0)
+    bracket_us = batch.event_overhead(100)
+    kernel_us = ms / max(launches, 1) * 1e3 - bracket_us
+    bytes_per_launch = BYTES_PER_FRAME * n * FRAMES
+    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9 if kernel_us > 0 else 0.0
+    plan = batch.plan(0)
+    out = {"workload": WORKLOADS["config5"].format(n=n), "instances_per_gpu": n, "instances_total": n * world,
+           "value": round(world * n * FRAMES * steps / elapsed / 1e6, 3), "unit": "Msamples/s", "steps": steps, "warmup": 32,
+           "ms_per_step": round(elapsed / steps * 1e3, 5),
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "kernel": batch.last_reverb_kernel, "kernel_us": round(kernel_us, 2), "launches_timed": launches,
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "reverbs_proven_steady": plan[1]}}
+    batch.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -76,6 +76,20 @@ int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* 
  * NULL for the batch's own stream) and returns without synchronising. */
 int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream);
 int oalsfx_batch_synchronize(oalsfx_batch* b);
+/* Api::mix for a caller that streams buffer after buffer from host memory (what the reference's only entry point is used for,
+ * src/oalsfxpp.cpp:3785-3829, src/oalsfxpp_test.cpp:891): returns as soon as the call is queued.  The copy in of call k + 1, the
+ * kernels of call k and the copy out of call k - 1 overlap on three streams, ordered by events.  `src_host` and `dst_host` must stay
+ * untouched until the call is through, which is the case once oalsfx_batch_wait has returned, or once three further
+ * oalsfx_batch_mix_async calls have (a call first waits for the one that used its staging slot three calls earlier).  The copies
+ * only run beside the kernels when the host buffers are page-locked (oalsfx_pinned_alloc, or the caller's own hipHostMalloc /
+ * hipHostRegister); pageable buffers work but serialise.  Property setters and apply_changes may be called between the calls as
+ * with oalsfx_batch_mix; they take effect from the next call on. */
+int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, float* dst_host);
+/* Waits until every queued oalsfx_batch_mix_async call has delivered its output. */
+int oalsfx_batch_wait(oalsfx_batch* b);
+/* Page-locked host memory for the two calls above (hipHostMalloc / hipHostFree), so that a caller need not link HIP itself. */
+void* oalsfx_pinned_alloc(unsigned long long bytes);
+void oalsfx_pinned_free(void* p);
 /* The batch's own HIP stream (a hipStream_t) so callers can bracket launches with their own events. */
 void* oalsfx_batch_stream(oalsfx_batch* b);
 
@@ -119,6 +133,9 @@ int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us);
  * 256 contiguous bytes per wave instruction), `repeats` launches of k_hbm_sweep, reading (write == 0) or writing.  Used under
  * rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE to calibrate those counters against a known byte count (profiles/README.md). */
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats);
+/* ---- measurement helper: the experiment switches of OALSFX_DEBUG_FLAGS (hip/batch.cpp: debug_flags), settable between calls so
+ * that one process can time two code paths side by side on the same box (scripts/ab_paths.py).  Process-wide. */
+void oalsfx_debug_set_flags(int flags);
 /* ---- measurement helper: the ring traffic of the steady-state reverb kernel without its arithmetic (k_stream_pattern:
  * per instance 24 unaligned read streams and 24 aligned write streams of 256 frames per launch, `dwords_per_lane` = 1, 2 or 4
  * consecutive dwords per lane = 256-, 512- or 1024-byte bursts; slabs `slab_floats` apart (>= 235520), instance i shifted by

@@ -35,6 +35,9 @@ class Batch:
         if getattr(self, "_h", None):
             self._lib.oalsfx_batch_destroy(self._h)
             self._h = None
+            for p in getattr(self, "_pinned", []):
+                self._lib.oalsfx_pinned_free(C.c_void_p(p))
+            self._pinned = []
 
     def __del__(self):
         self.close()
@@ -101,6 +104,27 @@ class Batch:
         dst = np.empty_like(src)
         self._check(self._lib.oalsfx_batch_mix(self._h, src.shape[1], src.ctypes.data_as(_fp), dst.ctypes.data_as(_fp)))
         return dst
+
+    def mix_async(self, src, dst):
+        """Queues one buffer from / to host arrays [n][frames][channels] (page-locked ones overlap with the kernels) and returns;
+        both must stay untouched until wait() or until three more mix_async calls have returned."""
+        assert src.dtype == np.float32 and dst.dtype == np.float32 and src.flags.c_contiguous and dst.flags.c_contiguous and src.shape == dst.shape
+        assert src.ndim == 3 and src.shape[0] == self.n and src.shape[2] == self.channels, src.shape
+        self._check(self._lib.oalsfx_batch_mix_async(self._h, src.shape[1], src.ctypes.data_as(_fp), dst.ctypes.data_as(_fp)))
+
+    def wait(self):
+        self._check(self._lib.oalsfx_batch_wait(self._h))
+
+    def pinned_array(self, frames):
+        """A page-locked float32 array [n][frames][channels] (freed with the returned array's base buffer: keep the Batch's library loaded)."""
+        count = self.n * frames * self.channels
+        p = self._lib.oalsfx_pinned_alloc(count * 4)
+        if not p:
+            raise BatchError("oalsfx_pinned_alloc failed")
+        buf = (C.c_float * count).from_address(p)
+        arr = np.frombuffer(buf, dtype=np.float32).reshape(self.n, frames, self.channels)
+        self._pinned = getattr(self, "_pinned", []) + [p]
+        return arr
 
     def mix_device(self, frames, src_ptr, dst_ptr, stream=None):
         """Buffers already in device memory (raw addresses, e.g. torch.Tensor.data_ptr()); asynchronous."""

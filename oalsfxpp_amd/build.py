@@ -12,8 +12,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(CSRC, "liboalsfx_hip.so")
-OBJ_DIR = os.path.join(ROOT, "build", "obj")
+# OALSFX_BUILD_TAG=<tag> (with OALSFX_EXTRA_FLAGS=-D...) builds an experiment variant beside the product for same-box A/B runs
+# (scripts/ab_libs.py): objects in build/obj_<tag>, library ab/liboalsfx_hip_<tag>.so
+_TAG = os.environ.get("OALSFX_BUILD_TAG", "")
+OUT = os.path.join(ROOT, "ab", f"liboalsfx_hip_{_TAG}.so") if _TAG else os.path.join(CSRC, "liboalsfx_hip.so")
+OBJ_DIR = os.path.join(ROOT, "build", "obj_" + _TAG if _TAG else "obj")
 
 HOST_SOURCES = ["host/props.cpp", "host/panning.cpp", "host/update.cpp", "host/hostabi.cpp", "host/api.cpp"]
 HIP_SOURCES = ["hip/batch.cpp", "hip/reverb.hip", "hip/support_kernels.hip", "hip/wave_effects.hip"]
@@ -46,6 +49,7 @@ def _newer(src, dst, extra=()):
 
 def build_all(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = _hipcc()
     headers = []
     for d in (os.path.join(ROOT, "include"), os.path.join(CSRC, "host"), os.path.join(CSRC, "hip")):
@@ -58,7 +62,7 @@ def build_all(force=False, verbose=False):
         objs.append(obj)
         if not (force or _newer(src, obj, headers)):
             continue
-        cmd = [hipcc] + COMMON + (DEVICE if rel in HIP_SOURCES else []) + EXTRA.get(rel, []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + COMMON + (DEVICE if rel in HIP_SOURCES else []) + EXTRA.get(rel, []) + os.environ.get("OALSFX_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((rel, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -96,4 +100,5 @@ def build_tools(force=False):
 
 if __name__ == "__main__":
     print(build_all(force="--force" in sys.argv, verbose=True))
-    print(build_tools(force="--force" in sys.argv))
+    if not _TAG:
+        print(build_tools(force="--force" in sys.argv))

@@ -122,6 +122,14 @@ struct oalsfx_batch {
     float* d_io_src = nullptr;
     float* d_io_dst = nullptr;
     size_t io_capacity = 0;
+    // ... and for the pipelined ones (oalsfx_batch_mix_async): kPipeDepth staging slots used in turn; the copy in, the kernels and the
+    // copy out of successive calls run on three streams, ordered by events only
+    static constexpr int kPipeDepth = 3;
+    struct PipeSlot { float* d_src = nullptr; float* d_dst = nullptr; hipEvent_t copied_in = nullptr, mixed = nullptr, copied_out = nullptr; bool busy = false; };
+    PipeSlot pipe[kPipeDepth];
+    size_t pipe_capacity = 0;
+    long long pipe_turn = 0;
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 
     unsigned long long* d_timeline = nullptr;    // measurement only (OALSFX_DEBUG_TIMELINE=<file>)
     // Parameter uploads: the changed records are packed into pinned memory, copied in one piece and scattered on the device;
@@ -508,12 +516,16 @@ bool ensure_mixbuf(oalsfx_batch* b)
     return b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
 }
 
+// Timing experiments only (OALSFX_DEBUG_FLAGS, or oalsfx_debug_set_flags for A/B runs inside one process): 8 every reverb through the
+// general kernel, 32 / 64 tap distances rounded to 128 / 256 bytes in the steady-state kernel (results wrong on purpose,
+// scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two
+// launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
+// through the believing builds)
+int g_debug_flags = -1;
 int debug_flags()
 {
-    // timing experiments only (OALSFX_DEBUG_FLAGS): 8 every reverb through the general kernel, 32 / 64 tap distances rounded
-    // to 128 / 256 bytes in the steady-state kernel (results wrong on purpose, scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two launches), 0x100000 no cooperative workgroups for the ring-light effects
-    static const int v = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
-    return v;
+    if (g_debug_flags < 0) g_debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
+    return g_debug_flags;
 }
 
 // Brackets one kernel launch with events recorded on its stream.  (Events attached to the launch itself through
@@ -922,6 +934,16 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     hipFree(b->d_hot); hipFree(b->d_inst_epoch); hipFree(b->d_exact);
+    if (b->h2d_stream) hipStreamSynchronize(b->h2d_stream);
+    if (b->d2h_stream) hipStreamSynchronize(b->d2h_stream);
+    for (auto& ps : b->pipe) {
+        hipFree(ps.d_src); hipFree(ps.d_dst);
+        if (ps.copied_in) hipEventDestroy(ps.copied_in);
+        if (ps.mixed) hipEventDestroy(ps.mixed);
+        if (ps.copied_out) hipEventDestroy(ps.copied_out);
+    }
+    if (b->h2d_stream) hipStreamDestroy(b->h2d_stream);
+    if (b->d2h_stream) hipStreamDestroy(b->d2h_stream);
     if (b->h_exact) (void)hipHostFree(b->h_exact);
     if (b->h_fault) (void)hipHostFree(b->h_fault);
     if (b->ev_exact) hipEventDestroy(b->ev_exact);
@@ -1066,6 +1088,73 @@ int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* 
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
     poll_exact(b);
     return check_fault(b) ? 1 : 0;
+}
+
+int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, float* dst_host)
+{
+    if (frames == 0) return 1;
+    if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
+    if (!src_host) return b->fail(kErrNoSrc) ? 1 : 0;
+    if (!dst_host) return b->fail(kErrNoDst) ? 1 : 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    const size_t floats = static_cast<size_t>(b->n) * frames * b->channels;
+    if (!b->h2d_stream) {
+        if (!b->hip_ok(hipStreamCreateWithFlags(&b->h2d_stream, hipStreamNonBlocking), "hipStreamCreate")) return 0;
+        if (!b->hip_ok(hipStreamCreateWithFlags(&b->d2h_stream, hipStreamNonBlocking), "hipStreamCreate")) return 0;
+        for (auto& ps : b->pipe) {
+            if (!b->hip_ok(hipEventCreateWithFlags(&ps.copied_in, hipEventDisableTiming), "hipEventCreate")) return 0;
+            if (!b->hip_ok(hipEventCreateWithFlags(&ps.mixed, hipEventDisableTiming), "hipEventCreate")) return 0;
+            if (!b->hip_ok(hipEventCreateWithFlags(&ps.copied_out, hipEventDisableTiming), "hipEventCreate")) return 0;
+        }
+    }
+    if (floats > b->pipe_capacity) {
+        // a larger call than any before: let the pipeline drain, then grow every slot
+        if (!b->hip_ok(hipStreamSynchronize(b->d2h_stream), "hipStreamSynchronize")) return 0;
+        for (auto& ps : b->pipe) {
+            hipFree(ps.d_src); hipFree(ps.d_dst);
+            ps.d_src = ps.d_dst = nullptr;
+            ps.busy = false;
+        }
+        b->pipe_capacity = 0;
+        for (auto& ps : b->pipe) {
+            if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&ps.d_src), floats * sizeof(float)), "hipMalloc(io)")) return 0;
+            if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&ps.d_dst), floats * sizeof(float)), "hipMalloc(io)")) return 0;
+        }
+        b->pipe_capacity = floats;
+    }
+    oalsfx_batch::PipeSlot& ps = b->pipe[b->pipe_turn++ % oalsfx_batch::kPipeDepth];
+    // the call that used this staging slot kPipeDepth calls ago must be through: its output copy is the last thing it does
+    if (ps.busy && !b->hip_ok(hipEventSynchronize(ps.copied_out), "hipEventSynchronize")) return 0;
+    ps.busy = true;
+    if (!b->hip_ok(hipMemcpyAsync(ps.d_src, src_host, floats * sizeof(float), hipMemcpyHostToDevice, b->h2d_stream), "hipMemcpyAsync(src)")) return 0;
+    if (!b->hip_ok(hipEventRecord(ps.copied_in, b->h2d_stream), "hipEventRecord")) return 0;
+    if (!b->hip_ok(hipStreamWaitEvent(b->stream, ps.copied_in, 0), "hipStreamWaitEvent")) return 0;
+    if (!mix_device(b, frames, ps.d_src, ps.d_dst, b->stream)) return 0;
+    if (!b->hip_ok(hipEventRecord(ps.mixed, b->stream), "hipEventRecord")) return 0;
+    if (!b->hip_ok(hipStreamWaitEvent(b->d2h_stream, ps.mixed, 0), "hipStreamWaitEvent")) return 0;
+    if (!b->hip_ok(hipMemcpyAsync(dst_host, ps.d_dst, floats * sizeof(float), hipMemcpyDeviceToHost, b->d2h_stream), "hipMemcpyAsync(dst)")) return 0;
+    return b->hip_ok(hipEventRecord(ps.copied_out, b->d2h_stream), "hipEventRecord") ? 1 : 0;
+}
+
+int oalsfx_batch_wait(oalsfx_batch* b)
+{
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (b->d2h_stream && !b->hip_ok(hipStreamSynchronize(b->d2h_stream), "hipStreamSynchronize")) return 0;
+    if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    for (auto& ps : b->pipe) ps.busy = false;
+    poll_exact(b);
+    return check_fault(b) ? 1 : 0;
+}
+
+void* oalsfx_pinned_alloc(unsigned long long bytes)
+{
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void oalsfx_pinned_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int oalsfx_batch_synchronize(oalsfx_batch* b)
@@ -1230,6 +1319,8 @@ int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)
     if (avg_us) *avg_us = total * 1e3 / repeats;
     return ok ? 1 : 0;
 }
+
+void oalsfx_debug_set_flags(int flags) { g_debug_flags = flags < 0 ? 0 : flags; }
 
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats)
 {

@@ -38,6 +38,10 @@ namespace {
 constexpr int kRow = 68;          // 4 (history prefix, 16-byte aligned data) + 64 samples
 constexpr int kGroups = 3;        // row groups, 4 lines each
 constexpr int kRngFloats = OALSFX_RV_MAX_UPDATE;
+#ifndef OALSFX_SPLIT_ISSUE
+#define OALSFX_SPLIT_ISSUE 1
+#endif
+constexpr int kSplitIssue = OALSFX_SPLIT_ISSUE; // the steady-state kernel requests a tile's ring data in one go (0), two halves (1) or four quarters (2): measurement switch
 
 // Per-wave table of instance constants kept in LDS (dword offsets).  The steady-state tile reads them
 // with broadcast ds_reads right where they are used: they cost no VALU slot and no long-lived SGPRs.
@@ -423,8 +427,6 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         go_all[wib] = go ? 1 : 0;
         eax_all[wib] = (go && eax) ? 1 : 0;
     }
-    stamp(); // [1] descriptors read, steady-state test done
-
     if (go) {
         // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
         // (flags >> 8) & 32 / 64: timing experiment only (OALSFX_DEBUG_FLAGS), taps rounded to 128 / 256 bytes, results wrong
@@ -498,7 +500,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         atomicAdd(ctx.fault, 1u); // the host listed an instance that is not steady: reported by the next synchronising call
     }
     } // !hit
-    stamp(); // [1'] tables in place (hot record or descriptors)
+    stamp(); // [1] hot record or descriptors read, steady-state test done, tables written
     // after the send-filter pre-pass an instance with a filter reads its sends' planes, any other instance the raw input
     const bool filtered = (flags & kFiltered) != 0 && has_filter;
     const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
@@ -553,6 +555,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         return lround_away(fv * sinus);
     };
     int md_next = 0, md_cur = 0;
+    // the early half of a tile's requests: the input frame, early taps, early all-pass, early line
     auto issue_loads = [&](unsigned t4x, int posx) {
         const int px = min(posx, frames - 1);
         if (MC) {
@@ -576,10 +579,23 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (filtered) n_w0 = wsrc[px];
         }
         if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN);
+        if (kSplitIssue >= 2) return;
         if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
         if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
-        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN);
+    };
+    auto issue_loads_q2 = [&](unsigned t4x) { // quarters: early all-pass and early line
+        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
+        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
+    };
+    auto issue_loads_q4 = [&](unsigned t4x) { // quarters: late all-pass
         if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
+    };
+    // ... and the late half (late taps, late all-pass, late line).  Issued apart from the first half (in P3 of the tile before; for
+    // the first tile in its own P1): a wavefront that issues all 25 requests of a tile in one go sits in the issue queue while its
+    // siblings and its own arithmetic wait.
+    auto issue_loads_late = [&](unsigned t4x) {
+        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN);
+        if (kSplitIssue < 2 && (!HY || !(late_mask & 16u))) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
         if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE);
     };
     auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
@@ -597,7 +613,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
     if (MD && go && mod_on) md_next = next_mod_delays(min(64, frames));
-    if (go) issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
+    if (go) {
+        issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
+        if (kSplitIssue >= 2) issue_loads_q2(static_cast<unsigned>(offset + lane) << 2);
+        if (!kSplitIssue) issue_loads_late(static_cast<unsigned>(offset + lane) << 2);
+    }
     stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
     stamp(); // [4]
@@ -644,7 +664,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
                 if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
             }
-            if (tile + 1 < tiles) issue_loads(t4 + 256u, pos + 64);
+            if (kSplitIssue && tile == 0) {
+                // the first tile's late half, straight into this tile's registers
+                if (!HY || !(late_mask & 8u)) p_lt = load4(t4, 3, OALSFX_RV_MAIN);
+                if (!HY || !(late_mask & 16u)) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
+                if (!HY || !(late_mask & 32u)) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
+            }
+            if (tile + 1 < tiles) {
+                issue_loads(t4 + 256u, pos + 64);
+                if (!kSplitIssue) issue_loads_late(t4 + 256u);
+            }
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
             float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
             if (MC) {
@@ -723,6 +752,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         stamp();
         lds_barrier();
         stamp();
+        if (kSplitIssue >= 2 && go && tile + 1 < tiles) {
+            issue_loads_q2(t4 + 256u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         int xg = 2;
         if (any_eax) {
             // ---------------- P2: feed-forward half of the second shelf ----------------
@@ -756,6 +789,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (go) {
             if (act) store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
             wave_sync();
+            if (kSplitIssue && tile + 1 < tiles) {
+                issue_loads_late(t4 + 256u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
             const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
@@ -857,6 +894,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         stamp();
         // ---------------- P4: second T60 feed-forward ----------------
         if (go) {
+            if (kSplitIssue >= 2 && tile + 1 < tiles) {
+                issue_loads_q4(t4 + 256u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
             const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TH1);
             const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
@@ -1005,8 +1046,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
+#ifndef OALSFX_FP_OCCUPANCY
+#define OALSFX_FP_OCCUPANCY 4
+#endif
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false>
-__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__global__ __launch_bounds__(64 * NW, (FP && !MD) ? OALSFX_FP_OCCUPANCY : 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
     reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);

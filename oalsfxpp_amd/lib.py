@@ -34,6 +34,10 @@ SIGNATURES = {
     "oalsfx_batch_mix": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
     "oalsfx_batch_mix_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oalsfx_batch_synchronize": (C.c_int, [C.c_void_p]),
+    "oalsfx_batch_mix_async": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "oalsfx_batch_wait": (C.c_int, [C.c_void_p]),
+    "oalsfx_pinned_alloc": (C.c_void_p, [C.c_ulonglong]),
+    "oalsfx_pinned_free": (None, [C.c_void_p]),
     "oalsfx_batch_stream": (C.c_void_p, [C.c_void_p]),
     "oalsfx_batch_read_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(desc.SlotParams), C.POINTER(desc.SlotState)]),
     "oalsfx_batch_read_ring": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, C.c_int]),
@@ -46,6 +50,7 @@ SIGNATURES = {
     "oalsfx_batch_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "oalsfx_debug_set_flags": (None, [C.c_int]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
     "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),

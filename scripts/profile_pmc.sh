@@ -5,6 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1
 mkdir -p $O
 cd $R
+export OALSFX_TRAFFIC_REFRESH=1   # bench.py must not insist on a traffic.json of this build: these passes produce it
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --steps 50 --warmup 64 --no-cpu-baseline > $O/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq2 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc2.log 2>&1

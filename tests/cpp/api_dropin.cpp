@@ -20,7 +20,7 @@ static void synth(uint32_t instance, uint32_t buffer_index, int count, float* ou
 
 #define CHECK(cond)                                                     \
     if (!(cond)) {                                                      \
-        std::fprintf(stderr, "check failed line %d: %s\n", __LINE__, #cond); \
+        std::fprintf(stderr, "check failed line %d: %s (last message: %s)\n", __LINE__, #cond, api.get_error_message()); \
         return 2;                                                       \
     }
 

@@ -19,7 +19,7 @@ HEADER = os.path.join(ROOT, "include", "oalsfx_hip.h")
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned)_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
