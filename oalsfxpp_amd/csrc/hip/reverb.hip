@@ -36,12 +36,9 @@ namespace oalsfx_hip {
 namespace {
 
 constexpr int kRow = 68;          // 4 (history prefix, 16-byte aligned data) + 64 samples
-constexpr int kGroups = 3;        // row groups, 4 lines each
+constexpr int kGroups = 3;        // row groups, 4 lines each (general path)
+constexpr int kSteadyGroups = 6;  // the steady-state kernel: three for the input half of a tile (shelves), three for its late half (T60)
 constexpr int kRngFloats = OALSFX_RV_MAX_UPDATE;
-#ifndef OALSFX_SPLIT_ISSUE
-#define OALSFX_SPLIT_ISSUE 1
-#endif
-constexpr int kSplitIssue = OALSFX_SPLIT_ISSUE; // the steady-state kernel requests a tile's ring data in one go (0), two halves (1) or four quarters (2): measurement switch
 
 // Per-wave table of instance constants kept in LDS (dword offsets).  The steady-state tile reads them
 // with broadcast ds_reads right where they are used: they cost no VALU slot and no long-lived SGPRs.
@@ -248,7 +245,10 @@ struct SteadyShared {
     // build's own extras need (modulation row, hand-over rows)
     static constexpr int kFpMisc = ut::SIZE + (MD ? 64 : 0) + (ST ? 8 * kRow : 0);
     // mono / stereo otherwise: sized for the general path, which non-steady instances fall back to
-    static constexpr int kFloats = FP ? kGroups * 4 * kRow + kFpMisc + 64 : MC ? kGroups * 4 * kRow + kMcBase + 160 : Lds<CH>::kFloats;
+    static constexpr int kSteadyFloats = kSteadyGroups * 4 * kRow + ut::SIZE + 64 + 8 * kRow; // rows, table, modulation row, hand-over rows
+    static constexpr int kFloats = FP ? kSteadyGroups * 4 * kRow + kFpMisc + 64
+                                 : MC ? kSteadyGroups * 4 * kRow + kMcBase + 160
+                                      : (Lds<CH>::kFloats > kSteadyFloats ? Lds<CH>::kFloats : kSteadyFloats);
     alignas(16) float lds_all[NW][kFloats];
     float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     int go_all[NW];
@@ -292,8 +292,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     const bool last = (flags & kLast) != 0;
 
     float* lds = lds_all[wib];
-    auto row = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };
-    float* utf = lds + kGroups * 4 * kRow;
+    auto rowI = [&](int group, int c) -> float* { return lds + (group * 4 + c) * kRow; };       // input half: send mix, shelves
+    auto rowL = [&](int group, int c) -> float* { return lds + ((3 + group) * 4 + c) * kRow; }; // late half: T60 sections
+    float* utf = lds + kSteadyGroups * 4 * kRow;
     unsigned* utu = reinterpret_cast<unsigned*>(utf);
 
     const int inst = (FP && ctx.list_first >= 0) ? ctx.list_first + (valid ? w : 0) : __builtin_amdgcn_readfirstlane(list[valid ? w : 0]);
@@ -555,8 +556,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         return lround_away(fv * sinus);
     };
     int md_next = 0, md_cur = 0;
-    // the early half of a tile's requests: the input frame, early taps, early all-pass, early line
-    auto issue_loads = [&](unsigned t4x, int posx) {
+    // the frame of a tile (its input half runs one iteration before its late half)
+    auto issue_input = [&](int posx) {
         const int px = min(posx, frames - 1);
         if (MC) {
 #pragma unroll
@@ -578,25 +579,19 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             n_in0 = src[px];
             if (filtered) n_w0 = wsrc[px];
         }
+    };
+    // the ring requests of a tile in three parts (S1, S3, S5 of the iteration before its late half)
+    auto issue_taps_a = [&](unsigned t4x) {
         if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN);
-        if (kSplitIssue >= 2) return;
         if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
+    };
+    auto issue_taps_b = [&](unsigned t4x) {
         if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
-    };
-    auto issue_loads_q2 = [&](unsigned t4x) { // quarters: early all-pass and early line
-        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
-        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
-    };
-    auto issue_loads_q4 = [&](unsigned t4x) { // quarters: late all-pass
-        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
-    };
-    // ... and the late half (late taps, late all-pass, late line).  Issued apart from the first half (in P3 of the tile before; for
-    // the first tile in its own P1): a wavefront that issues all 25 requests of a tile in one go sits in the issue queue while its
-    // siblings and its own arithmetic wait.
-    auto issue_loads_late = [&](unsigned t4x) {
         if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN);
-        if (kSplitIssue < 2 && (!HY || !(late_mask & 16u))) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
         if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE);
+    };
+    auto issue_taps_c = [&](unsigned t4x) {
+        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
     };
     auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
@@ -605,18 +600,18 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     };
     // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 4 * NW
     const int cw = (lane >> 2) & (NW - 1), cc = lane & 3;
-    float* crow0 = lds_all[cw] + (0 * 4 + cc) * kRow;
-    float* crow1 = lds_all[cw] + (1 * 4 + cc) * kRow;
-    float* crow2 = lds_all[cw] + (2 * 4 + cc) * kRow;
+    float* crowI0 = lds_all[cw] + (0 * 4 + cc) * kRow;
+    float* crowI1 = lds_all[cw] + (1 * 4 + cc) * kRow;
+    float* crowI2 = lds_all[cw] + (2 * 4 + cc) * kRow;
+    float* crowL1 = lds_all[cw] + (4 * 4 + cc) * kRow;
+    float* crowL2 = lds_all[cw] + (5 * 4 + cc) * kRow;
     float* cdat = chain_all[cw][cc];
 
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
-    if (MD && go && mod_on) md_next = next_mod_delays(min(64, frames));
     if (go) {
-        issue_loads(static_cast<unsigned>(offset + lane) << 2, lane);
-        if (kSplitIssue >= 2) issue_loads_q2(static_cast<unsigned>(offset + lane) << 2);
-        if (!kSplitIssue) issue_loads_late(static_cast<unsigned>(offset + lane) << 2);
+        issue_input(lane);
+        issue_taps_a(static_cast<unsigned>(offset + lane) << 2);
     }
     stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
@@ -632,30 +627,35 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     const int duty = (wib - group) & (NW - 1);
 
     const int tiles = any_go ? (RG ? (frames + 63) >> 6 : frames >> 6) : 0; // a workgroup without a steady instance skips the cooperative loop altogether
-    for (int tile = 0; tile < tiles; ++tile) {
-        const int pos = (tile << 6) + lane;
+    // The tile loop is skewed by one tile: iteration `it` runs the input half of tile it (P1, C1, P2, C2: send mix and input shelves, which
+    // depend on nothing but the input frames) together with the late half of tile it - 1 (P3, C3, P4, C4, P5: everything that touches the
+    // delay lines).  The chain phases of the two halves run at the same time on two different wavefronts of the workgroup, and a tile
+    // costs four workgroup barriers and two chain-phase latencies instead of eight and four; the first tile's shelves run while its
+    // ring requests travel.  The shelves' output of tile it waits in its own rows (rowI) for the next iteration's P3.
+    float o0 = 0.0F, o1 = 0.0F;
+    float outv[MC ? 8 : 1] = {}; // multichannel: the output frame being accumulated (of the tile whose late half runs)
+    for (int it = 0; it <= tiles && tiles > 0; ++it) {
+        const int ta = it, tb = it - 1;
+        const bool has_a = ta < tiles, has_b = tb >= 0;
+        const int pos_a = (ta << 6) + lane, pos_b = (tb << 6) + lane;
         // RG, the build for calls that are not a whole number of tiles: the last tile holds fewer samples; its lanes from L on
         // compute along but store nothing, and the recurrences stop at L.  (Its own build: with L a variable the chain loops and
         // the predicated stores cost the whole-tile case 6 %.)
-        const int L = RG ? min(64, frames - (tile << 6)) : 64;
-        const bool act = RG ? lane < L : true;
-        const unsigned t4 = static_cast<unsigned>(offset + pos) << 2;
-        float o0 = 0.0F, o1 = 0.0F;
-        float outv[MC ? 8 : 1] = {}; // multichannel: the output frame being accumulated
+        const int La = RG ? min(64, frames - (ta << 6)) : 64;
+        const int Lb = RG ? min(64, frames - (tb << 6)) : 64;
+        const bool act = RG ? lane < Lb : true;
+        const unsigned t4 = static_cast<unsigned>(offset + pos_b) << 2; // the late half's tile
+        float oa0 = 0.0F, oa1 = 0.0F;
+        float outva[MC ? 8 : 1] = {}; // the dry mix (or the running mix of the slots before) of tile ta
         v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
+        const int xg = eax ? 0 : 2; // where the shelves left their output
 
-        // ---------------- P1: inputs, A-format, feed-forward half of the first shelf ----------------
         if (go) {
-            const float in[2] = {n_in0, n_in1};
-            const float win[2] = {filtered ? n_w0 : n_in0, filtered ? n_w1 : n_in1}; // what the auxiliary send sees
-            float inv[MC ? 8 : 1], winv[MC ? 8 : 1];
-#pragma unroll
-            for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
             if (MD) {
-                md_cur = md_next;
-                if (mod_on && tile + 1 < tiles) md_next = next_mod_delays(min(64, frames - ((tile + 1) << 6)));
+                md_cur = md_next; // the delays of tile tb
+                if (mod_on && has_a) md_next = next_mod_delays(min(64, frames - (ta << 6))); // ... of tile ta, whose late-line requests go out below
             }
-            if (HY) {
+            if (HY && has_b) {
                 // groups with a tap closer than two tiles: requested now, after the previous tile's stores
                 if (late_mask & 1u) p_e = load4(t4, 0, OALSFX_RV_MAIN);
                 if (late_mask & 2u) p_a = load4(t4, 1, OALSFX_RV_EARLY_AP);
@@ -664,135 +664,17 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
                 if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
             }
-            if (kSplitIssue && tile == 0) {
-                // the first tile's late half, straight into this tile's registers
-                if (!HY || !(late_mask & 8u)) p_lt = load4(t4, 3, OALSFX_RV_MAIN);
-                if (!HY || !(late_mask & 16u)) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
-                if (!HY || !(late_mask & 32u)) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
-            }
-            if (tile + 1 < tiles) {
-                issue_loads(t4 + 256u, pos + 64);
-                if (!kSplitIssue) issue_loads_late(t4 + 256u);
-            }
+            // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts, S1 / S3 / S5: a wavefront
+            // that issues all 24 in one go sits in the issue queue while its siblings and its own arithmetic wait
+            if (has_a && it > 0) issue_taps_a(t4 + 256u); // (the prologue issued tile 0's)
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
-            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
-            if (MC) {
-                // dry mix and B-format send, channel by channel (reference mix_source, src/oalsfxpp.cpp:2917-2982)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    if (c >= nch) continue;
-                    if (first) {
-#pragma unroll
-                        for (int o = 0; o < 8; ++o)
-                            if (aud_dir & (1ULL << (c * 8 + o))) outv[MC ? o : 0] += inv[MC ? c : 0] * utf[kMcBase + 64 + c * 8 + o];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (aud_aux & (1ULL << (c * 4 + k))) wet[k] += winv[MC ? c : 0] * utf[kMcBase + 128 + c * 4 + k];
-                }
-                if (!first) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (c < nch) outv[MC ? c : 0] = mixbuf[c * OALSFX_MAX_CHUNK + pos];
-                }
-            } else if (!first) {
-                o0 = mixbuf[pos];
-                if (CH == 2) o1 = mixbuf[OALSFX_MAX_CHUNK + pos];
-            } else {
-                const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
-                const float g[4] = {gd.x, gd.y, gd.z, gd.w};
-#pragma unroll
-                for (int c = 0; c < (MC ? 0 : CH); ++c) {
-                    if (aud_dir & (1u << (c * 2 + 0))) o0 += in[c] * g[c * 2 + 0];
-                    if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) o1 += in[c] * g[c * 2 + 1];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < (MC ? 0 : CH); ++c) {
-                const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
-                const float g[4] = {ga.x, ga.y, ga.z, ga.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (aud_aux & (1u << (c * 4 + k))) wet[k] += win[c] * g[k];
-            }
-            v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
-            a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
-            a23 = a23 + wet[0] * v2f{b2a, b2a}; a23 = a23 + wet[1] * v2f{b2a, -b2a}; a23 = a23 + wet[2] * v2f{-b2a, b2a}; a23 = a23 + wet[3] * v2f{-b2a, -b2a};
-            if (lane < 4) {
-                const float* ch = chain_all[wib][lane];
-                row(0, lane)[3] = ch[coop::LPX0]; row(0, lane)[2] = ch[coop::LPX1];
-            }
-            row(0, 0)[4 + lane] = a01.x; row(0, 1)[4 + lane] = a01.y; row(0, 2)[4 + lane] = a23.x; row(0, 3)[4 + lane] = a23.y;
-            wave_sync();
-            {
-                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::LPB);
-                const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
-                const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
-                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
-                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
-                row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
-            }
-            if (lane < 4) {
-                float* ch = chain_all[wib][lane];
-                ch[coop::LPX1] = row(0, lane)[4 + L - 2]; ch[coop::LPX0] = row(0, lane)[4 + L - 1]; // L == 1: [3] is the old newest sample
-            }
         }
-        stamp();
-        lds_barrier();
-        stamp();
-        // ---------------- C1 (wave 0): feedback half of the first shelf, 16 chains ----------------
-        if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
-            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
-            float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
-            crow2[3] = y1; crow2[2] = y2; // history prefix for the second shelf's feed-forward half
-            biquad_chain(crow1, crow2, L, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
-            cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
-            __builtin_amdgcn_s_setprio(0);
-        }
-        stamp();
-        lds_barrier();
-        stamp();
-        if (kSplitIssue >= 2 && go && tile + 1 < tiles) {
-            issue_loads_q2(t4 + 256u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        int xg = 2;
-        if (any_eax) {
-            // ---------------- P2: feed-forward half of the second shelf ----------------
-            if (go && eax) {
-                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
-                const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
-                const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
-                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
-                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
-                row(1, 0)[4 + lane] = u01.x; row(1, 1)[4 + lane] = u01.y; row(1, 2)[4 + lane] = u23.x; row(1, 3)[4 + lane] = u23.y;
-            }
-            stamp();
-        lds_barrier();
-        stamp();
-            // ---------------- C2 (wave 1) ----------------
-            if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain2_on) {
-                __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
-                float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
-                biquad_chain(crow1, crow0, L, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
-                cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
-                __builtin_amdgcn_s_setprio(0);
-            }
-            stamp();
-        lds_barrier();
-        stamp();
-            if (eax) xg = 0;
-        }
-        // ---------------- P3: main delay write, early reflections, late taps, T60 first feed-forward ----------------
+        // ---------------- S1, late half: P3(tb): main delay write, early reflections, late taps, T60 first feed-forward ----------------
         v2f e01 = {0, 0}, e23 = {0, 0};
         float dg = 0.0F, ac = 0.0F, sx = 0.0F, sy = 0.0F;
-        if (go) {
-            if (act) store4(t4, OALSFX_RV_MAIN, row(xg, 0)[4 + lane], row(xg, 1)[4 + lane], row(xg, 2)[4 + lane], row(xg, 3)[4 + lane]);
+        if (go && has_b) {
+            if (act) store4(t4, OALSFX_RV_MAIN, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
             wave_sync();
-            if (kSplitIssue && tile + 1 < tiles) {
-                issue_loads_late(t4 + 256u);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
             const v4f ec = *reinterpret_cast<const v4f*>(utf + ut::ECOEF);
@@ -801,10 +683,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 // early taps shorter than the tile read what an earlier lane just wrote to the main delay: the shelves' output
                 const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4);
                 const int e0 = static_cast<int>(d.x >> 2), e1 = static_cast<int>(d.y >> 2), e2 = static_cast<int>(d.z >> 2), e3 = static_cast<int>(d.w >> 2);
-                if (lane >= e0) p_e.x = row(xg, 0)[4 + lane - e0];
-                if (lane >= e1) p_e.y = row(xg, 1)[4 + lane - e1];
-                if (lane >= e2) p_e.z = row(xg, 2)[4 + lane - e2];
-                if (lane >= e3) p_e.w = row(xg, 3)[4 + lane - e3];
+                if (lane >= e0) p_e.x = rowI(xg, 0)[4 + lane - e0];
+                if (lane >= e1) p_e.y = rowI(xg, 1)[4 + lane - e1];
+                if (lane >= e2) p_e.z = rowI(xg, 2)[4 + lane - e2];
+                if (lane >= e3) p_e.w = rowI(xg, 3)[4 + lane - e3];
             }
             if (ST && (short_mask & 2u)) {
                 // all-pass offsets shorter than the tile: the lanes whose sources lie in earlier tiles are right from the
@@ -863,67 +745,168 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             }
             const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
             const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
-            if (lane < 4) row(0, lane)[3] = chain_all[wib][lane][coop::T60X];
-            row(0, 0)[4 + lane] = u01.x; row(0, 1)[4 + lane] = u01.y; row(0, 2)[4 + lane] = u23.x; row(0, 3)[4 + lane] = u23.y;
+            if (lane < 4) rowL(0, lane)[3] = chain_all[wib][lane][coop::T60X];
+            rowL(0, 0)[4 + lane] = u01.x; rowL(0, 1)[4 + lane] = u01.y; rowL(0, 2)[4 + lane] = u23.x; rowL(0, 3)[4 + lane] = u23.y;
             wave_sync();
             {
                 const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TL0);
                 const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TL1);
-                const float* xa = row(0, 0) + 4 + lane; const float* xb = row(0, 1) + 4 + lane;
-                const float* xc = row(0, 2) + 4 + lane; const float* xd = row(0, 3) + 4 + lane;
+                const float* xa = rowL(0, 0) + 4 + lane; const float* xb = rowL(0, 1) + 4 + lane;
+                const float* xc = rowL(0, 2) + 4 + lane; const float* xd = rowL(0, 3) + 4 + lane;
                 const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
                 const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
-                row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+                rowL(1, 0)[4 + lane] = w01.x; rowL(1, 1)[4 + lane] = w01.y; rowL(1, 2)[4 + lane] = w23.x; rowL(1, 3)[4 + lane] = w23.y;
             }
-            if (lane < 4) chain_all[wib][lane][coop::T60X] = row(0, lane)[4 + L - 1];
+            if (lane < 4) chain_all[wib][lane][coop::T60X] = rowL(0, lane)[4 + Lb - 1];
+        }
+        // ---------------- S1, input half: P1(ta): inputs, A-format, feed-forward half of the first shelf ----------------
+        if (go && has_a) {
+            const float in[2] = {n_in0, n_in1};
+            const float win[2] = {filtered ? n_w0 : n_in0, filtered ? n_w1 : n_in1}; // what the auxiliary send sees
+            float inv[MC ? 8 : 1], winv[MC ? 8 : 1];
+#pragma unroll
+            for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
+            if (ta + 1 < tiles) issue_input(pos_a + 64); // the next tile's frame, now that this one's is in `in`
+            float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
+            if (MC) {
+                // dry mix and B-format send, channel by channel (reference mix_source, src/oalsfxpp.cpp:2917-2982)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (c >= nch) continue;
+                    if (first) {
+#pragma unroll
+                        for (int o = 0; o < 8; ++o)
+                            if (aud_dir & (1ULL << (c * 8 + o))) outva[MC ? o : 0] += inv[MC ? c : 0] * utf[kMcBase + 64 + c * 8 + o];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (aud_aux & (1ULL << (c * 4 + k))) wet[k] += winv[MC ? c : 0] * utf[kMcBase + 128 + c * 4 + k];
+                }
+                if (!first) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nch) outva[MC ? c : 0] = mixbuf[c * OALSFX_MAX_CHUNK + pos_a];
+                }
+            } else if (!first) {
+                oa0 = mixbuf[pos_a];
+                if (CH == 2) oa1 = mixbuf[OALSFX_MAX_CHUNK + pos_a];
+            } else {
+                const v4f gd = *reinterpret_cast<const v4f*>(utf + ut::GDIR);
+                const float g[4] = {gd.x, gd.y, gd.z, gd.w};
+#pragma unroll
+                for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                    if (aud_dir & (1u << (c * 2 + 0))) oa0 += in[c] * g[c * 2 + 0];
+                    if (CH == 2 && (aud_dir & (1u << (c * 2 + 1)))) oa1 += in[c] * g[c * 2 + 1];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                const v4f ga = *reinterpret_cast<const v4f*>(utf + ut::GAUX + 4 * c);
+                const float g[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (aud_aux & (1u << (c * 4 + k))) wet[k] += win[c] * g[k];
+            }
+            v2f a01 = {0.0F, 0.0F}, a23 = {0.0F, 0.0F};
+            a01 = a01 + wet[0] * v2f{b2a, b2a}; a01 = a01 + wet[1] * v2f{b2a, -b2a}; a01 = a01 + wet[2] * v2f{b2a, -b2a}; a01 = a01 + wet[3] * v2f{b2a, b2a};
+            a23 = a23 + wet[0] * v2f{b2a, b2a}; a23 = a23 + wet[1] * v2f{b2a, -b2a}; a23 = a23 + wet[2] * v2f{-b2a, b2a}; a23 = a23 + wet[3] * v2f{-b2a, -b2a};
+            if (lane < 4) {
+                const float* ch = chain_all[wib][lane];
+                rowI(0, lane)[3] = ch[coop::LPX0]; rowI(0, lane)[2] = ch[coop::LPX1];
+            }
+            rowI(0, 0)[4 + lane] = a01.x; rowI(0, 1)[4 + lane] = a01.y; rowI(0, 2)[4 + lane] = a23.x; rowI(0, 3)[4 + lane] = a23.y;
+            wave_sync();
+            {
+                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::LPB);
+                const float* xa = rowI(0, 0) + 4 + lane; const float* xb = rowI(0, 1) + 4 + lane;
+                const float* xc = rowI(0, 2) + 4 + lane; const float* xd = rowI(0, 3) + 4 + lane;
+                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                rowI(1, 0)[4 + lane] = u01.x; rowI(1, 1)[4 + lane] = u01.y; rowI(1, 2)[4 + lane] = u23.x; rowI(1, 3)[4 + lane] = u23.y;
+            }
+            if (lane < 4) {
+                float* ch = chain_all[wib][lane];
+                ch[coop::LPX1] = rowI(0, lane)[4 + La - 2]; ch[coop::LPX0] = rowI(0, lane)[4 + La - 1]; // La == 1: [3] is the old newest sample
+            }
         }
         stamp();
         lds_barrier();
         stamp();
-        // ---------------- C3 (wave 2): first T60 section ----------------
-        if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
-            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
+        // ---------------- S2: C1(ta), feedback half of the first shelf, beside C3(tb), first T60 section: 16 chains each, two wavefronts ----------------
+        if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_a) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
+            float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
+            crowI2[3] = y1; crowI2[2] = y2; // history prefix for the second shelf's feed-forward half
+            biquad_chain(crowI1, crowI2, La, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O1];
-            crow2[3] = prev; // the second section's feed-forward half needs o1[-1]
-            first_order_chain(crow1, crow2, 0, L, cdat[coop::T_L2], 1.0F, false, prev);
+            crowL2[3] = prev; // the second section's feed-forward half needs o1[-1]
+            first_order_chain(crowL1, crowL2, 0, Lb, cdat[coop::T_L2], 1.0F, false, prev);
             cdat[coop::T60O1] = prev;
             __builtin_amdgcn_s_setprio(0);
         }
         stamp();
         lds_barrier();
         stamp();
-        // ---------------- P4: second T60 feed-forward ----------------
-        if (go) {
-            if (kSplitIssue >= 2 && tile + 1 < tiles) {
-                issue_loads_q4(t4 + 256u);
-                __builtin_amdgcn_sched_barrier(0);
+        // ---------------- S3: P2(ta), feed-forward half of the second shelf; P4(tb), second T60 feed-forward ----------------
+        if (go && has_a) {
+            issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (any_eax) {
+            if (go && eax && has_a) {
+                const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
+                const float* xa = rowI(2, 0) + 4 + lane; const float* xb = rowI(2, 1) + 4 + lane;
+                const float* xc = rowI(2, 2) + 4 + lane; const float* xd = rowI(2, 3) + 4 + lane;
+                const v2f u01 = ((bq.x * v2f{xa[0], xb[0]}) + (bq.y * v2f{xa[-1], xb[-1]})) + (bq.z * v2f{xa[-2], xb[-2]});
+                const v2f u23 = ((bq.x * v2f{xc[0], xd[0]}) + (bq.y * v2f{xc[-1], xd[-1]})) + (bq.z * v2f{xc[-2], xd[-2]});
+                rowI(1, 0)[4 + lane] = u01.x; rowI(1, 1)[4 + lane] = u01.y; rowI(1, 2)[4 + lane] = u23.x; rowI(1, 3)[4 + lane] = u23.y;
             }
+        }
+        if (go && has_b) {
             const v4f c0 = *reinterpret_cast<const v4f*>(utf + ut::TH0);
             const v4f c1 = *reinterpret_cast<const v4f*>(utf + ut::TH1);
-            const float* xa = row(2, 0) + 4 + lane; const float* xb = row(2, 1) + 4 + lane;
-            const float* xc = row(2, 2) + 4 + lane; const float* xd = row(2, 3) + 4 + lane;
+            const float* xa = rowL(2, 0) + 4 + lane; const float* xb = rowL(2, 1) + 4 + lane;
+            const float* xc = rowL(2, 2) + 4 + lane; const float* xd = rowL(2, 3) + 4 + lane;
             const v2f w01 = (v2f{c0.x, c0.y} * v2f{xa[0], xb[0]}) + (v2f{c1.x, c1.y} * v2f{xa[-1], xb[-1]});
             const v2f w23 = (v2f{c0.z, c0.w} * v2f{xc[0], xd[0]}) + (v2f{c1.z, c1.w} * v2f{xc[-1], xd[-1]});
-            row(1, 0)[4 + lane] = w01.x; row(1, 1)[4 + lane] = w01.y; row(1, 2)[4 + lane] = w23.x; row(1, 3)[4 + lane] = w23.y;
+            rowL(1, 0)[4 + lane] = w01.x; rowL(1, 1)[4 + lane] = w01.y; rowL(1, 2)[4 + lane] = w23.x; rowL(1, 3)[4 + lane] = w23.y;
         }
         stamp();
         lds_barrier();
         stamp();
-        // ---------------- C4 (wave 3): second T60 section and mid gain ----------------
-        if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (tile & 1) * 4 : 0)) && chain_on) {
-            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' tile phases on this SIMD
+        // ---------------- S4: C2(ta) beside C4(tb), second T60 section and mid gain ----------------
+        if (any_eax) {
+            if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain2_on && has_a) {
+                __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
+                float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
+                biquad_chain(crowI1, crowI0, La, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
+                cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
+            __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O2];
-            first_order_chain(crow1, crow1, 0, L, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+            first_order_chain(crowL1, crowL1, 0, Lb, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
             cdat[coop::T60O2] = prev;
             __builtin_amdgcn_s_setprio(0);
         }
         stamp();
         lds_barrier();
         stamp();
-        // ---------------- P5: late all-pass, ring writes, outputs ----------------
-        if (go) {
-            const v2f i01 = {row(1, 0)[4 + lane], row(1, 1)[4 + lane]};
-            const v2f i23 = {row(1, 2)[4 + lane], row(1, 3)[4 + lane]};
+        // ---------------- S5: P5(tb): late all-pass, ring writes, outputs ----------------
+        if (go && has_a) {
+            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (go && has_b) {
+            const v2f i01 = {rowL(1, 0)[4 + lane], rowL(1, 1)[4 + lane]};
+            const v2f i23 = {rowL(1, 2)[4 + lane], rowL(1, 3)[4 + lane]};
             if (ST && (short_mask & 16u)) {
                 // late all-pass offsets shorter than the tile, as for the early all-pass
                 const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 16);
@@ -965,11 +948,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 } else if (last) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if (c < nch) dst[static_cast<size_t>(pos) * nch + c] = outv[MC ? c : 0];
+                        if (c < nch) dst[static_cast<size_t>(pos_b) * nch + c] = outv[MC ? c : 0];
                 } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if (c < nch) mixbuf[c * OALSFX_MAX_CHUNK + pos] = outv[MC ? c : 0];
+                        if (c < nch) mixbuf[c * OALSFX_MAX_CHUNK + pos_b] = outv[MC ? c : 0];
                 }
             }
 #pragma unroll
@@ -983,14 +966,17 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (MC || !act) {
                 // stored above / a lane past the end of a ragged call's last tile
             } else if (last) {
-                if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(o0, o1);
-                else dst[pos] = o0;
+                if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos_b) * 2) = make_float2(o0, o1);
+                else dst[pos_b] = o0;
             } else {
-                mixbuf[pos] = o0;
-                if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos] = o1;
+                mixbuf[pos_b] = o0;
+                if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos_b] = o1;
             }
             wave_sync(); // ring stores of this tile precede the loads of the tile after next (program order)
         }
+        o0 = oa0; o1 = oa1;
+#pragma unroll
+        for (int c = 0; c < (MC ? 8 : 1); ++c) outv[c] = outva[c];
         stamp();
     }
 
