@@ -226,25 +226,17 @@ __device__ __forceinline__ void send_history_follow(const KernelCtx& ctx, int in
     }
 }
 
-// The same for a kernel that already knows which sends are enabled (bit 0 the direct send, bit 1 + s the send to slot s): no
-// parameter loads at the end of the launch.
-__device__ __forceinline__ void send_history_follow_listed(const KernelCtx& ctx, int inst, int c, int channels, int frames, const float* src,
-                                                           unsigned send_mask)
+// The same for a kernel that already knows which sends are enabled (bit 0 the direct send, bit 1 + s the send to slot s) and holds
+// the call's last two frames of channel c in registers (calls of two frames or more): no loads at the end of the launch.
+__device__ __forceinline__ void send_history_follow_values(const KernelCtx& ctx, int inst, int c, unsigned send_mask, float newest, float older)
 {
-    if (frames <= 0) return;
     oalsfx_source_state& S = ctx.source_state[inst];
-    const float newest = src[static_cast<size_t>(frames - 1) * channels + c];
-    const float older = frames >= 2 ? src[static_cast<size_t>(frames - 2) * channels + c] : 0.0F;
     for (int send = 0; send <= ctx.slots; ++send) {
         if (!((send_mask >> send) & 1u)) continue;
         oalsfx_hist_t* h[2] = {&S.lp[send][c], &S.hp[send][c]};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (frames >= 2) {
-                h[k]->x[1] = older; h[k]->y[1] = older;
-            } else {
-                h[k]->x[1] = h[k]->x[0]; h[k]->y[1] = h[k]->y[0];
-            }
+            h[k]->x[1] = older; h[k]->y[1] = older;
             h[k]->x[0] = newest; h[k]->y[0] = newest;
         }
     }

@@ -320,10 +320,22 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned epoch_now = 0;
     unsigned* miscu = reinterpret_cast<unsigned*>(utf + (FP ? SH::kFpMisc : 0)); // FP: image of the record's MISC block
     bool hit = false;
+    float early_in0 = 0.0F, early_in1 = 0.0F; // FP: the first tile's frame, requested beside the hot record
+    float hist_new[2] = {0.0F, 0.0F}, hist_old[2] = {0.0F, 0.0F}; // FP: the call's last two frames per channel, for the send filters' histories
     if constexpr (FP) {
         // ---- the hot record: 1 KiB, one 16-byte load per lane, straight into the LDS tables ----
         const v4u* rec = reinterpret_cast<const v4u*>(ctx.hot + sidx * hot::SIZE);
         const v4u r = rec[lane];
+        // the first tile's frame does not depend on the record (unless the send-filter pre-pass ran): it travels beside it
+        if (!(flags & kFiltered)) {
+            const float* raw = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+            if (CH == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(raw + static_cast<size_t>(lane) * 2);
+                early_in0 = v.x; early_in1 = v.y;
+            } else {
+                early_in0 = raw[lane];
+            }
+        }
         epoch_now = __builtin_amdgcn_readfirstlane(ctx.inst_epoch[inst]);
         const int offset_now = __builtin_amdgcn_readfirstlane(S.offset);
         if (lane < 32) *reinterpret_cast<v4u*>(utu + 4 * lane) = r;
@@ -610,7 +622,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
     if (go) {
-        issue_input(lane);
+        if (FP && !(flags & kFiltered)) { n_in0 = early_in0; n_in1 = early_in1; }
+        else issue_input(lane);
         issue_taps_a(static_cast<unsigned>(offset + lane) << 2);
     }
     stamp(); // [3] first requests issued
@@ -664,7 +677,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
                 if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
             }
-            // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts, S1 / S3 / S5: a wavefront
+            // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts (top and end of S1, S3): a wavefront
             // that issues all 24 in one go sits in the issue queue while its siblings and its own arithmetic wait
             if (has_a && it > 0) issue_taps_a(t4 + 256u); // (the prologue issued tile 0's)
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
@@ -767,6 +780,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #pragma unroll
             for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
             if (ta + 1 < tiles) issue_input(pos_a + 64); // the next tile's frame, now that this one's is in `in`
+            if (FP && ta + 1 == tiles) {
+                // the call's last two frames, for the histories of the pass-through send filters (no loads in the epilogue)
+#pragma unroll
+                for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                    hist_new[c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(in[c]), 63));
+                    hist_old[c] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(in[c]), 62));
+                }
+            }
             float wet[4] = {0.0F, 0.0F, 0.0F, 0.0F};
             if (MC) {
                 // dry mix and B-format send, channel by channel (reference mix_source, src/oalsfxpp.cpp:2917-2982)
@@ -829,6 +850,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 ch[coop::LPX1] = rowI(0, lane)[4 + La - 2]; ch[coop::LPX0] = rowI(0, lane)[4 + La - 1]; // La == 1: [3] is the old newest sample
             }
         }
+        if (go && has_a) {
+            issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2); // on their way while the chain phases run
+            __builtin_amdgcn_sched_barrier(0);
+        }
         stamp();
         lds_barrier();
         stamp();
@@ -854,7 +879,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         stamp();
         // ---------------- S3: P2(ta), feed-forward half of the second shelf; P4(tb), second T60 feed-forward ----------------
         if (go && has_a) {
-            issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2);
+            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (any_eax) {
@@ -900,10 +925,6 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         lds_barrier();
         stamp();
         // ---------------- S5: P5(tb): late all-pass, ring writes, outputs ----------------
-        if (go && has_a) {
-            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         if (go && has_b) {
             const v2f i01 = {rowL(1, 0)[4 + lane], rowL(1, 1)[4 + lane]};
             const v2f i23 = {rowL(1, 2)[4 + lane], rowL(1, 3)[4 + lane]};
@@ -999,7 +1020,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (MD && mod_on) S.mod_filter = mod_f;
         }
         if (FP) {
-            if (first && !filtered && lane < nch) send_history_follow_listed(ctx, inst, lane, nch, frames, src, send_mask);
+            if (first && !filtered && lane < nch)
+                send_history_follow_values(ctx, inst, lane, send_mask, lane == 0 ? hist_new[0] : hist_new[CH - 1], lane == 0 ? hist_old[0] : hist_old[CH - 1]);
         } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
     }
     if constexpr (FP) {
