@@ -25,7 +25,8 @@ def med(v):
 
 
 batches = []
-for _ in range(2):
+for flags in (fa, fb):
+    so.oalsfx_debug_set_flags(flags)   # in force while the batch settles: what ends up in the hot records (tap tables) is built under them
     b = Batch(n, desc.FMT_STEREO, 48000, 1)
     b.set_effect_type(0, desc.EAX_REVERB)
     b.apply_changes()
@@ -34,9 +35,10 @@ for _ in range(2):
     for k, s in enumerate(src):
         b.fill_synthetic(F, k, s.data_ptr())
     b.synchronize()
-    for k in range(8):
-        b.mix_device(F, src[k % 4].data_ptr(), dst.data_ptr())
-    b.synchronize()
+    for _ in range(3):
+        for k in range(8):
+            b.mix_device(F, src[k % 4].data_ptr(), dst.data_ptr())
+        b.synchronize()
     batches.append((b, src, dst))
 res = {0: [], 1: []}
 names = {}
