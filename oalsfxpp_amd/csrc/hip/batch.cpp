@@ -520,7 +520,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // general kernel, 32 / 64 tap distances rounded to 128 / 256 bytes in the steady-state kernel (results wrong on purpose,
 // scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two
 // launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
-// through the believing builds)
+// through the believing builds), 0x400000 ring-light workgroups in list (type) order instead of longest first
 int g_debug_flags = -1;
 int debug_flags()
 {
@@ -605,23 +605,33 @@ int wave_segments(const oalsfx_batch* b, int slot, int first_type, oalsfx_hip::W
 {
     seg = oalsfx_hip::WaveSegments{};
     const bool coop_allowed = !(debug_flags() & 0x100000);
-    int total = 0;
-    auto add = [&](int count, bool coop) {
+    const bool longest_first = !(debug_flags() & 0x400000);
+    // how long a workgroup of the type runs, relative (4096 instances of one type, 256-frame buffers, profiles/: microseconds)
+    static const int kCost[OALSFX_REVERB] = {8, 15, 26, 10, 10, 40, 21, 25, 15, 18}; // null, chorus, compressor, dedicated x 2, distortion, echo, equalizer, flanger, ring modulator
+    struct Part { int count, offset, cost; bool coop; };
+    Part parts[oalsfx_hip::WaveSegments::kMax];
+    int n = 0, total = 0;
+    auto add = [&](int count, bool coop, int cost) {
         if (count <= 0) return;
-        seg.count[seg.n] = count;
-        if (coop) seg.coop_mask |= 1u << seg.n;
+        parts[n++] = Part{count, total, cost, coop};
         total += count;
-        seg.n += 1;
     };
     for (int t = first_type; t < OALSFX_REVERB; ++t) {
         const int count = b->list_count[slot][t];
         if (coop_allowed && cooperative_type(t) && count >= 4) {
-            add(count & ~3, true);
-            add(count & 3, false);
+            add(count & ~3, true, kCost[t]);
+            add(count & 3, false, kCost[t]);
         } else {
-            add(count, false);
+            add(count, false, kCost[t]);
         }
     }
+    if (longest_first) std::stable_sort(parts, parts + n, [](const Part& x, const Part& y) { return x.cost > y.cost; });
+    for (int k = 0; k < n; ++k) {
+        seg.count[k] = parts[k].count;
+        seg.offset[k] = parts[k].offset;
+        if (parts[k].coop) seg.coop_mask |= 1u << k;
+    }
+    seg.n = n;
     return total;
 }
 

@@ -102,6 +102,10 @@ __device__ __forceinline__ void store_hist(const float* xrow, const float* yrow,
     h.y[1] = yrow[2]; h.y[0] = yrow[3];
 }
 
+// Bodies that deliver a tile's output one call late declare `static constexpr int kLag = 1` (see wave_instance).
+template <class T, class = void> struct LagOf { static constexpr int value = 0; };
+template <class T> struct LagOf<T, decltype(void(T::kLag))> { static constexpr int value = T::kLag; };
+
 // What a body sees of its instance.
 struct Inst {
     ConstSlotParams* sp;
@@ -564,13 +568,18 @@ struct DistortionW {
         }
         wave_sync();
     }
-    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L)
+    // The body lags by one tile (kLag): a call takes the B-format send of tile k (L frames, none in the flushing call behind the
+    // last tile) and adds to `out` the output of tile k - 1 (Lp frames, none in the first call).  The low-pass chain of tile k
+    // and the band-pass chain of tile k - 1 do not depend on each other: they run in the same chain phase on two lanes per
+    // instance, so a tile costs one 256-step recurrence instead of two in a row.
+    static constexpr int kLag = 1;
+    template <int CH> __device__ void tile(const Inst& I, const float* wet, float* out, int L, int Lp)
     {
         const auto& p = I.sp->u.distortion;
         const int lane = I.lane;
         float* lp = I.lds; float* sh = I.lds + kArr; float* bp = I.lds + 2 * kArr;
-        const int n = 4 * L;
-        {
+        const int n = 4 * L, np = 4 * Lp;
+        if (L > 0) {
             // low-pass feed-forward sums of this frame's four oversampled inputs (X, 0, 0, 0)
             const Coef c = coef(p.low_pass);
             const float X = wet[0] * 4.0F;
@@ -583,20 +592,36 @@ struct DistortionW {
             u.z = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * X);
             u.w = ((c.b0 * z) + (c.b1 * z)) + (c.b2 * z);
             *reinterpret_cast<float4*>(lp + 4 + 4 * lane) = u;
-            chain_phase(I, 1, [n](float* lds, int) { chain_biquad(lds, 0, n, lds[0], lds[1]); });
         }
-        const float fc = p.edge_coeff;
+        // line 0: the low-pass recurrence of this tile; line 1: the band-pass recurrence of the tile before (whose feed-forward
+        // sums the call before left in its row); the same code on two lanes
+        chain_phase(I, 2, [n, np](float* lds, int line) {
+            float* row = lds + (line ? 2 * kArr : 0);
+            chain_biquad(row, 0, line ? np : n, row[0], row[1]);
+        });
+        if (Lp > 0) {
+            const float kept = bp[4 + 4 * lane];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int k = m * 64 + lane;
-            float smp = lp[4 + k];
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp))) * -1.0F;
-            smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
-            sh[4 + k] = smp;
+            for (int c = 0; c < CH; ++c) {
+                const float g = p.gains[c] * p.attenuation;
+                if (c < I.channels && audible(g)) out[c] += g * kept;
+            }
         }
         wave_sync();
-        {
+        if (lane == 0) advance_row(bp, np); // the band-pass outputs become history before the row takes this tile's sums
+        wave_sync();
+        if (L > 0) {
+            const float fc = p.edge_coeff;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int k = m * 64 + lane;
+                float smp = lp[4 + k];
+                smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
+                smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp))) * -1.0F;
+                smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
+                sh[4 + k] = smp;
+            }
+            wave_sync();
             const Coef c = coef(p.band_pass);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -604,21 +629,11 @@ struct DistortionW {
                 const float* x = sh + 4 + k;
                 bp[4 + k] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
             }
-            chain_phase(I, 1, [n](float* lds, int) {
-                float* row = lds + 2 * kArr;
-                chain_biquad(row, 0, n, row[0], row[1]);
-            });
+            wave_sync();
+            if (lane < 2) advance_row(I.lds + lane * kArr, n);
+            x_hist0 = 0.0F; x_hist1 = 0.0F;
+            wave_sync();
         }
-        const float kept = bp[4 + 4 * lane];
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const float g = p.gains[c] * p.attenuation;
-            if (c < I.channels && audible(g)) out[c] += g * kept;
-        }
-        wave_sync();
-        if (lane < 3) advance_row(I.lds + lane * kArr, n);
-        if (L > 0) { x_hist0 = 0.0F; x_hist1 = 0.0F; }
-        wave_sync();
     }
     __device__ void finish(const Inst& I)
     {
@@ -724,9 +739,32 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
                 if (c < channels) n_mix[c] = mixbuf[c * OALSFX_MAX_CHUNK + p];
         }
     };
+    auto store_tile = [&](const float* o, int p, bool a) {
+        if (!a) return;
+        if (last) {
+            if (CH == 2) {
+                *reinterpret_cast<float2*>(dst + static_cast<size_t>(p) * 2) = make_float2(o[0], o[CH - 1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c < channels) dst[static_cast<size_t>(p) * channels + c] = o[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < channels) mixbuf[c * OALSFX_MAX_CHUNK + p] = o[c];
+        }
+    };
+    // A body may lag by one tile (Fx::kLag == 1, the distortion): its call for tile k delivers the output of tile k - 1, and one
+    // more call behind the last tile delivers the rest.  The mix so far of a tile is held back until its effect output arrives.
+    constexpr int kLag = LagOf<Fx>::value;
+    float held[CH];
+    int held_pos = 0, held_L = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) held[c] = 0.0F;
     request(0);
-    for (int base = 0; base < frames; base += 64) {
-        const int L = min(64, frames - base);
+    for (int base = 0; base < frames + (kLag ? 64 : 0); base += 64) {
+        const int L = base < frames ? min(64, frames - base) : 0;
         const bool act = lane < L;
         const int pos = base + lane;
         float in[CH], win[CH], out[CH];
@@ -761,23 +799,18 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
             for (int c = 0; c < CH; ++c) out[c] = mix[c];
         }
         stamp();
-        fx.template tile<CH>(I, wet, out, L);
-        stamp();
-
-        if (act) {
-            if (last) {
-                if (CH == 2) {
-                    *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos) * 2) = make_float2(out[0], out[CH - 1]);
-                } else {
+        if constexpr (kLag != 0) {
+            fx.template tile<CH>(I, wet, held, L, held_L);
+            stamp();
+            store_tile(held, held_pos, lane < held_L);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        if (c < channels) dst[static_cast<size_t>(pos) * channels + c] = out[c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CH; ++c)
-                    if (c < channels) mixbuf[c * OALSFX_MAX_CHUNK + pos] = out[c];
-            }
+            for (int c = 0; c < CH; ++c) held[c] = out[c];
+            held_pos = pos;
+            held_L = L;
+        } else {
+            fx.template tile<CH>(I, wet, out, L);
+            stamp();
+            store_tile(out, pos, act);
         }
     }
 
@@ -828,17 +861,16 @@ __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int s
     Group group{false, wib, block & 3, lds_group, lds_stride};
     int w = block * 4 + wib;
     if (seg.n > 0) {
-        int k = 0, first_block = 0, offset = 0;
+        int k = 0, first_block = 0;
         for (; k + 1 < seg.n; ++k) {
             const int b = (seg.count[k] + 3) >> 2;
             if (block < first_block + b) break;
             first_block += b;
-            offset += seg.count[k];
         }
         const int local = (block - first_block) * 4 + wib;
         group.coop = ((seg.coop_mask >> k) & 1u) != 0;
         if (local >= seg.count[k]) return; // never in a cooperative segment: those hold whole workgroups only
-        w = offset + local;
+        w = seg.offset[k] + local;
     } else if (w >= count) {
         return; // whole wavefronts leave; no workgroup barrier on this path
     }
