@@ -772,7 +772,9 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
             const bool mixed = light > 0 && steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
             // the proven-steady builds: mono / stereo, whole tiles, a launch of their own
-            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && !(debug_flags() & 0x200000);
+            // ... and only when every steady instance of the slot is proven: a second steady launch beside it costs a fork and a join
+            // on this stack (about 27 us), far more than the believing builds cost the proven instances
+            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && b->slow_count[s] == 0 && !(debug_flags() & 0x200000);
             const int fast = use_fast ? b->fast_count[s] : 0;
             // parts: ring-light effects | proven-steady reverbs | believed-steady reverbs (all steady ones where the proven builds
             // are not in play) | general reverbs

@@ -220,25 +220,35 @@ struct ModDelayW {
             v[k] = in;
             if (lane < L && d[k] != 0 && !inside[k]) v[k] = buf[static_cast<unsigned>(o - d[k]) & mask];
         }
+        // both sides walk the tile together: a side with a short delay needs many rounds (64 / delay), each one a ballot and a
+        // lane permute whose latencies the other side's round hides
+        float val[2] = {0.0F, 0.0F}; // what this lane's sample leaves in the two rings
+        t[0] = t[1] = 0.0F;
+        int s[2] = {0, 0};
+        while (s[0] < L || s[1] < L) {
+            int e[2];
+            float handed[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool blocked = lane >= s[k] && lane < L && inside[k] && lane - d[k] >= s[k];
+                const unsigned long long nb = __ballot(blocked);
+                e[k] = nb ? static_cast<int>(__builtin_ctzll(nb)) : L;
+                handed[k] = __shfl(val[k], inside[k] ? lane - d[k] : lane);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (lane >= s[k] && lane < L && lane < e[k]) {
+                    if (inside[k]) v[k] = handed[k];
+                    t[k] = v[k] * fb;
+                    val[k] = in + t[k];
+                }
+                s[k] = max(s[k], e[k]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            float val = 0.0F; // what this lane's sample leaves in the ring
-            t[k] = 0.0F;
-            for (int s = 0; s < L;) {
-                const bool pending = lane >= s && lane < L;
-                const bool blocked = pending && inside[k] && lane - d[k] >= s;
-                const unsigned long long nb = __ballot(blocked);
-                const int e = nb ? static_cast<int>(__builtin_ctzll(nb)) : L;
-                const float handed = __shfl(val, inside[k] ? lane - d[k] : lane);
-                if (pending && lane < e) {
-                    if (inside[k]) v[k] = handed;
-                    t[k] = v[k] * fb;
-                    val = in + t[k];
-                }
-                s = e;
-            }
-            if (lane < L) buf[static_cast<unsigned>(o) & mask] = val;
+            if (lane < L) buf[static_cast<unsigned>(o) & mask] = val[k];
         }
         // left tap before right tap for every output (reference :4193-4208)
 #pragma unroll
@@ -457,14 +467,15 @@ struct EchoW {
     int offset;
     float n_t1, n_t2;   // taps of the next tile, requested one tile ahead when both taps are at least two tiles long
     bool have_next;
-    int block;          // samples per sub-block: no longer than the shorter tap (in a cooperative workgroup: than anybody's)
+    int block;          // samples per sub-block: no longer than the tap the feedback runs through, tap2 (in a cooperative workgroup: than
+                        // anybody's); tap1 only listens, what it hears inside the tile is read when the tile is complete
     __device__ void init(const Inst& I)
     {
         const auto& p = I.sp->u.echo;
         offset = I.ss->u.echo.offset;
         n_t1 = n_t2 = 0.0F;
         have_next = false;
-        block = max(1, min(64, min(p.tap1, p.tap2)));
+        block = max(1, min(64, p.tap2 > 0 ? p.tap2 : 64));
         if (I.lane == 0) {
             load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
             float* yrow = I.lds + kRow; // the recurrence's coefficients travel with its row
@@ -508,7 +519,6 @@ struct EchoW {
             const int e = min(L, s + block);
             const bool mine = lane >= s && lane < e;
             if (mine) {
-                if (in1) t1 = wrow[4 + lane - p.tap1];
                 if (in2) t2 = wrow[4 + lane - p.tap2];
                 xrow[4 + lane] = t2 + wet[0];
             }
@@ -525,6 +535,7 @@ struct EchoW {
             wave_sync();
         }
         if (lane < L) I.ring[static_cast<unsigned>(o) & mask] = wrow[4 + lane];
+        if (in1 && lane < L) t1 = wrow[4 + lane - p.tap1];
 #pragma unroll
         for (int ch = 0; ch < CH; ++ch) {
             if (ch >= I.channels) continue;
