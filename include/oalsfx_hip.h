@@ -136,6 +136,9 @@ int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, i
 /* ---- measurement helper: the experiment switches of OALSFX_DEBUG_FLAGS (hip/batch.cpp: debug_flags), settable between calls so
  * that one process can time two code paths side by side on the same box (scripts/ab_paths.py).  Process-wide. */
 void oalsfx_debug_set_flags(int flags);
+/* ---- measurement helper: device address of a slot's delay-line slab (0 if it has none): where a batch's slabs land in memory
+ * moves the reverb kernel's launch time by a few per cent (scripts/placement_bench.py). */
+unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int slot);
 /* ---- measurement helper: the ring traffic of the steady-state reverb kernel without its arithmetic (k_stream_pattern:
  * per instance 24 unaligned read streams and 24 aligned write streams of 256 frames per launch, `dwords_per_lane` = 1, 2 or 4
  * consecutive dwords per lane = 256-, 512- or 1024-byte bursts; slabs `slab_floats` apart (>= 235520), instance i shifted by

@@ -1332,6 +1332,13 @@ int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)
     return ok ? 1 : 0;
 }
 
+unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int slot)
+{
+    if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
+    return reinterpret_cast<unsigned long long>(b->h_rings[static_cast<size_t>(instance) * b->slots + slot]);
+}
+
 void oalsfx_debug_set_flags(int flags) { g_debug_flags = flags < 0 ? 0 : flags; }
 
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats)

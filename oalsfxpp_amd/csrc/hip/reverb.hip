@@ -870,7 +870,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O1];
             crowL2[3] = prev; // the second section's feed-forward half needs o1[-1]
+#ifndef OALSFX_ABLATE_T60_CHAINS // timing experiment (scripts/README: upper bound of what a parallel prefix of these sections could save; results wrong)
             first_order_chain(crowL1, crowL2, 0, Lb, cdat[coop::T_L2], 1.0F, false, prev);
+#endif
             cdat[coop::T60O1] = prev;
             __builtin_amdgcn_s_setprio(0);
         }
@@ -917,7 +919,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O2];
+#ifndef OALSFX_ABLATE_T60_CHAINS
             first_order_chain(crowL1, crowL1, 0, Lb, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+#endif
             cdat[coop::T60O2] = prev;
             __builtin_amdgcn_s_setprio(0);
         }

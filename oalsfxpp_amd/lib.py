@@ -51,6 +51,7 @@ SIGNATURES = {
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "oalsfx_debug_set_flags": (None, [C.c_int]),
+    "oalsfx_debug_ring_address": (C.c_ulonglong, [C.c_void_p, C.c_int, C.c_int]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
     "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),

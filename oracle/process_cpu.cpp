@@ -342,6 +342,10 @@ void process_ringmod(const oalsfx_ringmod_params& p, oalsfx_ringmod_state& s, in
 // ---------------------------------------------------------------------------------------------
 // Reverb / EAX reverb (reference src/oalsfxpp.cpp:6078-6170 and 7358-7903)
 // ---------------------------------------------------------------------------------------------
+#ifdef OALSFX_ORACLE_PS
+static long ps_tiles = 0, ps_used = 0; // experiment build: reverb blocks seen / evaluated the parallel-prefix way
+#endif
+
 struct Reverb {
     const oalsfx_reverb_params& p;
     oalsfx_reverb_state& s;
@@ -451,6 +455,51 @@ struct Reverb {
             s.mod_index = index;
             s.mod_filter = range;
 
+#ifdef OALSFX_ORACLE_PS
+            // EXPERIMENT (scripts/ps_error.py), never the parity build: the two first-order T60 sections evaluated the way a
+            // wavefront parallel prefix would, 64 samples at a time -- each sample an affine map x -> a x + b, composed in six
+            // doubling steps in fp32 (BASELINE's north_star suggests this for the first-order sections); everything else as the
+            // reference.  Only where a tile's inputs lie entirely before it (steady state, taps of 64 samples or more).
+            float ps_out[4][OALSFX_RV_MAX_UPDATE];
+            bool ps = !faded;
+            for (int j = 0; j < 4; ++j)
+                ps = ps && s.cur_late_tap[j] - p.late_feed_tap >= 64 && s.cur_late_tap[j] >= 64 && s.cur_late_line_off[j] - 64 >= 64;
+            ps_tiles += 1;
+            if (ps) {
+                ps_used += 1;
+                for (int base = 0; base < todo; base += 64) {
+                    const int n = std::min(64, todo - base);
+                    for (int j = 0; j < 4; ++j) {
+                        float u[64], a[64], b[64], na[64], nb[64];
+                        for (int i = 0; i < n; ++i) {
+                            const int off = off0 + base + i;
+                            u[i] = line(OALSFX_RV_MAIN, j)[(off - s.cur_late_tap[j]) & mask(OALSFX_RV_MAIN)] * p.density_gain;
+                            u[i] += line(OALSFX_RV_LATE_LINE, j)[(off - moddelay[base + i] - s.cur_late_line_off[j]) & mask(OALSFX_RV_LATE_LINE)];
+                        }
+                        float* st = &s.t60[j][0][0];
+                        for (int section = 0; section < 2; ++section) {
+                            const float* c = section ? p.t60_hf[j] : p.t60_lf[j];
+                            const float x_before = st[2 * section], y_before = st[2 * section + 1];
+                            for (int i = 0; i < n; ++i) {
+                                a[i] = c[2];
+                                b[i] = (c[0] * u[i]) + (c[1] * (i ? u[i - 1] : x_before)); // the feed-forward half, per lane
+                            }
+                            for (int d = 1; d < 64; d <<= 1) {
+                                for (int i = 0; i < n; ++i) {
+                                    na[i] = a[i]; nb[i] = b[i];
+                                    if (i >= d) { na[i] = a[i] * a[i - d]; nb[i] = (a[i] * b[i - d]) + b[i]; }
+                                }
+                                for (int i = 0; i < n; ++i) { a[i] = na[i]; b[i] = nb[i]; }
+                            }
+                            st[2 * section] = u[n - 1];
+                            for (int i = 0; i < n; ++i) u[i] = (a[i] * y_before) + b[i]; // the section's outputs feed the next one
+                            st[2 * section + 1] = u[n - 1];
+                        }
+                        for (int i = 0; i < n; ++i) ps_out[j][base + i] = p.t60_mid[j] * u[i];
+                    }
+                }
+            }
+#endif
             float fade = fade0;
             for (int i = 0; i < todo; ++i) {
                 const int off = off0 + i;
@@ -460,6 +509,11 @@ struct Reverb {
                 const int delayed = off - moddelay[i];
                 for (int j = 0; j < 4; ++j)
                     f[j] += tap(faded, OALSFX_RV_LATE_LINE, j, delayed - s.cur_late_line_off[j], delayed - p.late_line_off[j], fade);
+#ifdef OALSFX_ORACLE_PS
+                if (ps) {
+                    for (int j = 0; j < 4; ++j) f[j] = ps_out[j][i];
+                } else
+#endif
                 for (int j = 0; j < 4; ++j) {
                     // two first-order sections then the mid-band gain (src/oalsfxpp.cpp:7691-7719)
                     float* st = &s.t60[j][0][0];
@@ -709,5 +763,9 @@ double oracle_bench(void* h, int n_instances, int frames, int warmup, int buffer
     for (auto p : inst) delete p;
     return std::chrono::duration<double>(t1 - t0).count();
 }
+
+#ifdef OALSFX_ORACLE_PS
+void oracle_ps_counts(long* blocks, long* used) { *blocks = ps_tiles; *used = ps_used; }
+#endif
 
 } // extern "C"
