@@ -239,13 +239,13 @@ __device__ __forceinline__ void lds_barrier()
 template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true>
 struct SteadyShared {
     static constexpr bool MC = CH > 2;
-    static constexpr int kMcBase = ut::SIZE + 64 + 8 * kRow; // multichannel tables behind the modulation row and the hand-over rows:
-                                                             // GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
+    static constexpr int kMcBase = ut::SIZE + 8 * kRow; // multichannel tables behind the hand-over rows (the modulation row shares the first of
+                                                        // them): GOUT8 [8 stage-lines][8 channels], GDIR8 [8][8], GAUX8 [8][4]
     // FP (proven-steady instances only, nothing falls back inside): the rows, the table, the record's odds and ends, and what the
     // build's own extras need (modulation row, hand-over rows)
-    static constexpr int kFpMisc = ut::SIZE + (MD ? 64 : 0) + (ST ? 8 * kRow : 0);
+    static constexpr int kFpMisc = ut::SIZE + (ST ? 8 * kRow : MD ? 64 : 0);
     // mono / stereo otherwise: sized for the general path, which non-steady instances fall back to
-    static constexpr int kSteadyFloats = kSteadyGroups * 4 * kRow + ut::SIZE + 64 + 8 * kRow; // rows, table, modulation row, hand-over rows
+    static constexpr int kSteadyFloats = kSteadyGroups * 4 * kRow + ut::SIZE + 8 * kRow; // rows, table, hand-over rows (the modulation row is the first of them)
     static constexpr int kFloats = FP ? kSteadyGroups * 4 * kRow + kFpMisc + 64
                                  : MC ? kSteadyGroups * 4 * kRow + kMcBase + 160
                                       : (Lds<CH>::kFloats > kSteadyFloats ? Lds<CH>::kFloats : kSteadyFloats);
@@ -545,8 +545,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     };
     // modulated late line (reference calc_modulation_delays, src/oalsfxpp.cpp:7443-7470): delay of this lane's sample in
     // the tile after the ones already prepared; the smoother's chain is strictly sequential, tile after tile
+    // ST build: 8 hand-over rows behind the table; the modulation smoother's row (MD) lives only inside next_mod_delays and shares the first
+    auto strow = [&](int k) -> float* { return utf + ut::SIZE + k * kRow; };
     float* modrow = utf + ut::SIZE;
-    auto strow = [&](int k) -> float* { return utf + ut::SIZE + 64 + k * kRow; }; // ST build: 8 hand-over rows
     int mod_tiles = 0;
     auto next_mod_delays = [&](int samples_or_64) -> int { // RG: what the tile holds (a ragged call's last tile holds fewer than 64)
         const int samples = RG ? samples_or_64 : 64;

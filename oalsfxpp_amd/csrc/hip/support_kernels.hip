@@ -1,5 +1,7 @@
 // Kernels around the effect bodies: the send-filter pre-pass, the benchmark's synthetic input generator and two
 // measurement helpers.  (The effect bodies live in reverb.hip and wave_effects.hip.)
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace oalsfx_hip {
@@ -292,6 +294,26 @@ void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, 
     if (count <= 0) return;
     hipLaunchKernelGGL(k_scatter_records, dim3(count), dim3(64), 0, stream, static_cast<unsigned*>(dst), static_cast<int>(record_bytes / 4),
                        static_cast<const unsigned*>(packed), indices, count);
+}
+
+// ---- buffer copies between page-locked host memory and device memory as a kernel (oalsfx_batch_mix_async): the copy engines of some
+// hosts run the two directions far below the link's rate when both are busy; a grid of wavefronts reading or writing the mapped host
+// buffer does not depend on them.  16 bytes per lane, grid-stride.
+__global__ __launch_bounds__(256) void k_copy_floats(float* __restrict__ dst, const float* __restrict__ src, size_t floats)
+{
+    const size_t quads = floats >> 2;
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < quads; i += stride) d4[i] = s4[i];
+    for (size_t i = (quads << 2) + static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < floats; i += stride) dst[i] = src[i];
+}
+
+void launch_copy_floats(float* dst, const float* src, size_t floats, hipStream_t stream)
+{
+    if (floats == 0) return;
+    const int blocks = static_cast<int>(std::min<size_t>(128, (floats / 4 + 255) / 256 + 1)); // a few dozen wavefronts saturate the link; leave the chip to the effects
+    hipLaunchKernelGGL(k_copy_floats, dim3(blocks), dim3(256), 0, stream, dst, src, floats);
 }
 
 // ---- an empty kernel: what an event pair around a launch measures beyond the kernel itself ----

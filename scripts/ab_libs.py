@@ -2,7 +2,7 @@
 """Same box, same process: two builds of liboalsfx_hip.so timed alternately on the headline workload (one batch per build, resident
 together), many rounds; per round the average HIP-event duration of the steady-state reverb launch, then the median over rounds.
 
-    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets]
+    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets] [frames per call]
 
 Raw ctypes on both libraries (two builds cannot share the Python mirror's single handle)."""
 import ctypes as C
@@ -18,7 +18,7 @@ from oalsfxpp_amd import desc  # noqa: E402
 paths = [os.path.abspath(p) for p in sys.argv[1:3]]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 workload = sys.argv[4] if len(sys.argv) > 4 else "eax"
-F = 256
+F = int(sys.argv[5]) if len(sys.argv) > 5 else 256   # frames per call
 
 
 class Lib:
@@ -83,9 +83,9 @@ libs = [Lib(paths[w]) for w in order]
 rounds = {0: [], 1: []}
 for rnd in range(12):
     for k in (0, 1, 2, 3) if rnd % 2 == 0 else (3, 2, 1, 0):
-        libs[k].run(16)
+        libs[k].run(16 if F <= 512 else 4)
         libs[k].sync()
-        rounds[order[k]].append(libs[k].timed(64))
+        rounds[order[k]].append(libs[k].timed(64 if F <= 512 else 16))
 pair = C.c_double(0.0)
 libs[1].so.oalsfx_batch_event_overhead(libs[1].h, 200, C.byref(pair))
 for which in (0, 1):

@@ -7,7 +7,7 @@ echo "profiles done" >> $O/progress.txt
 cd $R
 python3 bench.py --host-io 20 > $O/bench_default.json 2> $O/bench_default.err
 echo "default bench done" >> $O/progress.txt
-for w in "--preset-mix" "--workload config3" "--workload config4" "--instances 32768"; do
+for w in "--preset-mix" "--workload config3" "--workload config4" "--workload config5"; do
   python3 bench.py $w --no-cpu-baseline 2>/dev/null | tail -1 >> $O/bench_other_workloads.json
 done
 echo "other benches done" >> $O/progress.txt
