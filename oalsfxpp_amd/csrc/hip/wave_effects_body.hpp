@@ -79,6 +79,37 @@ __device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a
     }
 }
 
+// o[i] = x[i] + c * o[i - 1] over row[4 .. 4 + n) in place, o[-1] = row[3]: sixteen samples at a time in registers, the next sixteen
+// requested before the current ones are worked on (two dependent instructions per sample, no LDS latency in the recurrence).
+__device__ __forceinline__ void chain_first_order(float* row, int n, float c)
+{
+    float prev = row[3];
+    int i = 0;
+    if (n >= 16) {
+        float4* r4 = reinterpret_cast<float4*>(row + 4);
+        float4 c0 = r4[0], c1 = r4[1], c2 = r4[2], c3 = r4[3];
+        auto step4 = [&](float4& v) {
+            v.x = v.x + (c * prev);
+            v.y = v.y + (c * v.x);
+            v.z = v.z + (c * v.y);
+            v.w = v.w + (c * v.z);
+            prev = v.w;
+        };
+        for (; i + 16 <= n; i += 16) {
+            const int q = i >> 2;
+            float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (i + 32 <= n) { n0 = r4[q + 4]; n1 = r4[q + 5]; n2 = r4[q + 6]; n3 = r4[q + 7]; }
+            step4(c0); step4(c1); step4(c2); step4(c3);
+            r4[q + 0] = c0; r4[q + 1] = c1; r4[q + 2] = c2; r4[q + 3] = c3;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+    }
+    for (; i < n; ++i) {
+        prev = row[4 + i] + (c * prev);
+        row[4 + i] = prev;
+    }
+}
+
 // Moves the last two of the n samples a row received into its history prefix.
 __device__ __forceinline__ void advance_row(float* row, int n)
 {
@@ -225,6 +256,32 @@ struct ModDelayW {
         float val[2] = {0.0F, 0.0F}; // what this lane's sample leaves in the two rings
         t[0] = t[1] = 0.0F;
         int s[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            // A delay of a few samples would take 64 / delay such rounds.  Where every in-tile source of a side lies the same d
+            // samples back (the LFO moves slowly: the usual case), sample i depends on i - d, i - 2d, ...: d independent chains,
+            // which d lanes walk through an LDS row, each a serial multiply-add per step -- 64 / d steps of two dependent
+            // instructions instead of 64 / d rounds of ballot and permute.
+            const unsigned long long in_tile = __ballot(inside[k] && lane < L);
+            if (in_tile == 0ULL) continue;
+            const int d0 = __builtin_amdgcn_readlane(d[k], static_cast<int>(__builtin_ctzll(in_tile)));
+            if (d0 > 16 || __ballot(lane >= d0 && lane < L && d[k] != d0) != 0ULL) continue;
+            // chain c = i % d0 gets a row of its own: its head (the one sample that reads the ring) in the row's prefix slot [3], the
+            // samples behind it in order from [4] on, so that the chain lane walks contiguous floats in register blocks
+            const int chain = lane % d0, step = lane / d0; // step 0: head
+            float* row = I.lds + chain * kRow;
+            const float head_t = v[k] * fb;
+            if (lane < L) row[3 + step] = step == 0 ? in + head_t : in;
+            wave_sync();
+            if (lane < d0 && lane < L) chain_first_order(I.lds + lane * kRow, (L - lane + d0 - 1) / d0 - 1, fb);
+            wave_sync();
+            if (lane < L) {
+                val[k] = row[3 + step];
+                t[k] = step == 0 ? head_t : row[2 + step] * fb; // what the sample d0 before left in the ring, fed back
+            }
+            wave_sync();
+            s[k] = L;
+        }
         while (s[0] < L || s[1] < L) {
             int e[2];
             float handed[2];
