@@ -68,9 +68,8 @@ enum {
 // entries, four per workgroup (a segment starts a new workgroup).  A segment whose bit is set in coop_mask holds whole
 // workgroups of one effect type, which run their filter recurrences together (wave_effects_body.hpp, chain_phase).
 // n == 0: no segments, wavefront w takes list entry w.
-// The segments are given in the order the grid's workgroups take them, which need not be the list's: the host puts the effect
-// types whose workgroups run longest first (the hardware hands workgroups out in index order, and a long one started late is the
-// tail of the launch); offset[k] says where segment k starts in the list.
+// The segments are given in the order the grid's workgroups take them, which need not be the list's (an experiment switch puts the
+// effect types whose workgroups run longest first; list order measured faster); offset[k] says where segment k starts in the list.
 struct WaveSegments {
     enum { kMax = 20 }; // ten ring-light types, each at most a cooperative part and a remainder
     int n;
