@@ -213,6 +213,8 @@ void release_slab(oalsfx_batch* b, size_t idx)
     }
 }
 
+int debug_flags(); // experiment / test switches, defined below
+
 constexpr int kSettleFrames = OALSFX_RV_FADE_SAMPLES; // the cross-fade (128 frames) is over, and with it at least one call, whose end
                                                       // snaps the output gains to their targets (reference MixHelpers::mix)
 
@@ -436,7 +438,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
                 const size_t idx = static_cast<size_t>(i) * b->slots + s;
                 const int t = b->h_params[idx].type;
                 if (t < OALSFX_REVERB) return t;
-                const int cls = !reverb_settled(b, idx) ? kGeneral : b->proven[idx] ? kFast : kSlow;
+                const bool force = (debug_flags() & 0x2000000) != 0; // test of the fault path only: every reverb counts as proven
+                const int cls = force ? kFast : !reverb_settled(b, idx) ? kGeneral : b->proven[idx] ? kFast : kSlow;
                 return cls + (t - OALSFX_REVERB);
             };
             for (int i = 0; i < b->n; ++i) count[bucket(i)] += 1;
@@ -521,7 +524,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two
 // launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
 // through the believing builds), 0x400000 ring-light workgroups longest type first instead of in list (type) order, 0x800000 oalsfx_batch_mix_async copies page-locked
-// buffers with kernels instead of the runtime's copy engines
+// buffers with kernels instead of the runtime's copy engines, 0x2000000 every reverb listed as proven steady whatever the device said
+// (exercises the fault counter of the FP builds: tests only)
 int g_debug_flags = -1;
 int debug_flags()
 {

@@ -510,7 +510,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
         wave_sync(); // this wave's table is complete: the first tile's requests below read it
     } else if (FP && valid && lane == 0) {
-        atomicAdd(ctx.fault, 1u); // the host listed an instance that is not steady: reported by the next synchronising call
+        // the host listed an instance that is not steady: reported by the next synchronising call (the counter lives in host memory)
+        __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     } // !hit
     stamp(); // [1] hot record or descriptors read, steady-state test done, tables written

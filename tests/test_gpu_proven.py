@@ -171,3 +171,21 @@ def test_proven_path_without_waiting_for_the_stream():
                 assert ok, f"instance {i} buffer {k}: {nbad} samples differ"
         for i, s in shadows.items():
             assert not s.compare_state(), f"instance {i}: state differs"
+
+
+def test_a_broken_host_invariant_is_reported_not_hidden():
+    """The FP builds have no general path to fall back to.  If the host ever listed an instance that is not steady (here forced with a
+    test switch: fresh instances, still cross-fading), the kernel counts it and the next synchronising call fails loudly."""
+    from oalsfxpp_amd import lib
+    from oalsfxpp_amd.api import BatchError
+    so = lib.load()
+    so.oalsfx_debug_set_flags(0x2000000)
+    try:
+        with Batch(5, desc.FMT_STEREO, 48000, 1) as b:
+            b.set_effect_type(0, desc.EAX_REVERB)
+            b.apply_changes()
+            x = np.zeros((5, 256, 2), dtype=np.float32)
+            with pytest.raises(BatchError, match="proven steady"):
+                b.mix(x)
+    finally:
+        so.oalsfx_debug_set_flags(0)
