@@ -19,3 +19,15 @@ python3 scripts/send_filter_bench.py 2>/dev/null | grep -v "^$" > $O/send_filter
 python3 scripts/update_storm_bench.py 2>/dev/null | grep updates > $O/update_storm.txt
 echo "all done" >> $O/progress.txt
 cat $O/trace/t_kernel_stats.csv | cut -c1-200
+# round 2 additions
+python3 scripts/host_io_bench.py 2>/dev/null | grep oalsfx > $O/host_io.txt || true
+python3 scripts/config4_parts.py 2>/dev/null | grep instances > $O/config4_parts.txt || true
+python3 scripts/chorus_delay_bench.py 2>/dev/null | grep us > $O/chorus_delays.txt || true
+if [ -f ab/liboalsfx_hip_r01.so ]; then
+  python3 scripts/ab_libs.py ab/liboalsfx_hip_r01.so oalsfxpp_amd/csrc/liboalsfx_hip.so 2>/dev/null | grep -v amdgpu > $O/ab_round1_vs_round2.txt || true
+  python3 scripts/ab_libs.py ab/liboalsfx_hip_r01.so oalsfxpp_amd/csrc/liboalsfx_hip.so 4096 presets 2>/dev/null | grep -v amdgpu > $O/ab_round1_vs_round2_presets.txt || true
+fi
+OALSFX_TRAFFIC_REFRESH=1 OALSFX_DEBUG_TIMELINE=/tmp/tl.bin python3 bench.py --steps 20 --warmup 64 --no-cpu-baseline --host-io 0 > $O/bench_timeline_build.json 2>/dev/null || true
+K=$(python3 -c "import json; print([json.loads(l) for l in open('$O/bench_timeline_build.json') if l.startswith('{')][-1]['roofline']['kernel_us'])")
+python3 scripts/timeline.py /tmp/tl.bin $K > $O/timeline_steady_kernel.txt || true
+echo "round 2 additions done" >> $O/progress.txt
