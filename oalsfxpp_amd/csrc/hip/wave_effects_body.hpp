@@ -537,7 +537,7 @@ struct EchoW {
             load_hist(I.lds, I.lds + kRow, I.ss->u.echo.filter);
             float* yrow = I.lds + kRow; // the recurrence's coefficients travel with its row
             yrow[0] = p.filter.a1; yrow[1] = p.filter.a2;
-            reinterpret_cast<int*>(I.lds + kCoefBase)[0] = block;
+            if (I.coop) reinterpret_cast<int*>(I.lds + kCoefBase)[0] = block;
         }
         wave_sync();
         if (I.coop) {
