@@ -335,6 +335,9 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": None, "kernel": "all effect kernels of a step (algorithmic bytes of the step / step time)",
                     "kernel_us": round(step_s * 1e6, 2), "launches_timed": args.steps, "algorithmic_bytes_per_launch": bytes_per_step}
+    pc, pk, pbest, pworst = batch.placement()
+    roofline["delay_line_placement"] = {"chunks": pc, "candidates_probed": pk, "probe_us_kept": round(pbest, 2), "probe_us_slowest_seen": round(pworst, 2),
+                                        "note": "the runtime keeps the fastest of a few candidate allocations for the delay lines (traffic-only probe; DESIGN 2)"}
     roofline["launch_plan_last_slot"] = {"ring_light": plan[0], "reverbs_proven_steady": plan[1], "reverbs_believed_steady": plan[2],
                                          "reverbs_general": plan[3]}
 

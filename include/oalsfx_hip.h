@@ -120,6 +120,9 @@ int oalsfx_batch_kernel_timing_samples(oalsfx_batch* b, int effect_type, double*
  * ring-light kernels, [1] reverbs proven steady (the builds without fallback), [2] reverbs believed steady, [3] reverbs on
  * the general kernel.  Nothing the reference has a counterpart for; tests and bench.py use it to say which kernel they measured. */
 int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4]);
+/* What the placement search for the delay-line chunks did: chunks allocated, candidates probed, and the traffic-only probe's
+ * microseconds per launch on the candidate kept last and on the slowest one seen next to it (0 when no search ran). */
+int oalsfx_batch_placement(const oalsfx_batch* b, int* chunks, int* candidates, double* best_us, double* worst_us);
 /* Symbol of the steady-state reverb kernel launched last, with its template arguments as rocprofv3 prints them ("" before the first). */
 const char* oalsfx_batch_last_reverb_kernel(const oalsfx_batch* b);
 /* PCI bus id ("0000:c1:00.0") of a HIP device ordinal, for benchmark records that must show N distinct GPUs.  Returns 1 on success. */
@@ -139,6 +142,13 @@ void oalsfx_debug_set_flags(int flags);
 /* ---- measurement helper: device address of a slot's delay-line slab (0 if it has none): where a batch's slabs land in memory
  * moves the reverb kernel's launch time by a few per cent (scripts/placement_bench.py). */
 unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int slot);
+/* ---- measurement helper: moves every delay-line chunk of the batch to a fresh allocation (contents copied, slab table updated);
+ * keep_old != 0 leaves the old chunk allocated so that the next move lands elsewhere again.  Synchronises. */
+int oalsfx_debug_move_rings(oalsfx_batch* b, int keep_old);
+/* ---- measurement helper: k_stream_pattern (above) on the batch's own delay-line chunk, `repeats` launches, average microseconds per
+ * launch.  Overwrites the delay lines: for placement experiments only. */
+int oalsfx_debug_probe_rings(oalsfx_batch* b, int repeats, double* avg_us);
+int oalsfx_debug_probe_pointer(void* slabs, int instances, int slab_floats, int repeats, double* avg_us);
 /* ---- measurement helper: the ring traffic of the steady-state reverb kernel without its arithmetic (k_stream_pattern:
  * per instance 24 unaligned read streams and 24 aligned write streams of 256 frames per launch, `dwords_per_lane` = 1, 2 or 4
  * consecutive dwords per lane = 256-, 512- or 1024-byte bursts; slabs `slab_floats` apart (>= 235520), instance i shifted by

@@ -182,6 +182,13 @@ class Batch:
         self._check(self._lib.oalsfx_batch_plan(self._h, slot, c))
         return tuple(c)
 
+    def placement(self):
+        """(chunks, candidates probed, probe us on the chunk kept, probe us on the slowest candidate seen) of the delay-line placement search."""
+        c, k = C.c_int(0), C.c_int(0)
+        a, w = C.c_double(0.0), C.c_double(0.0)
+        self._lib.oalsfx_batch_placement(self._h, C.byref(c), C.byref(k), C.byref(a), C.byref(w))
+        return c.value, k.value, a.value, w.value
+
     @property
     def last_reverb_kernel(self):
         return (self._lib.oalsfx_batch_last_reverb_kernel(self._h) or b"").decode()

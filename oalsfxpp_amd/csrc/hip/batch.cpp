@@ -117,6 +117,11 @@ struct oalsfx_batch {
     int general_count[OALSFX_MAX_SLOTS] = {};
     std::map<size_t, RingPool> pools;
     std::vector<void*> chunks;
+    struct RingChunk { char* base; size_t bytes; void* alloc; };
+    std::vector<RingChunk> ring_chunks;            // the slab pools' chunks (for oalsfx_debug_move_rings)
+    // placement search (place_ring_chunk): what it did for this batch, for benchmark records
+    int placed_chunks = 0, placement_candidates = 0;
+    double placement_best_us = 0.0, placement_worst_us = 0.0;
 
     // staging for host-pointer mixes
     float* d_io_src = nullptr;
@@ -279,6 +284,78 @@ void advance_settling(oalsfx_batch* b, int frames)
     b->settling.resize(keep);
 }
 
+// `chunks` zero-filled chunks of `count` delay-line slabs each, appended to `out`.  Where such a chunk lands in the card's memory is not
+// the same everywhere: the reverb's ring traffic (48 streams per instance, a few hundred thousand in all) runs at one of three rates
+// depending on the physical pages behind it, up to 15 % apart, about a third of the card each (scripts/vram_map.py,
+// profiles/README.md) -- and the steady-state kernel follows the traffic-only probe to the microsecond
+// (scripts/move_rings_probe.py).  So for chunks of 1 GiB and more the runtime does not take the first allocations it is given: it
+// allocates candidates (all held, or the driver would hand the same pages out again), times the probe on each (k_ring_probe, which
+// leaves the memory zero-filled), stops once it holds enough of the fastest kind and has seen a clearly slower one (or after
+// 2 * chunks + 4 candidates, or half the free memory), keeps the fastest and frees the rest.  A few hundred milliseconds, once per
+// batch.  OALSFX_DEBUG_FLAGS 0x4000000 switches the search off.
+bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_floats, std::vector<float*>& out)
+{
+    if (chunks <= 0) return true;
+    const size_t bytes = static_cast<size_t>(count) * slab_floats * sizeof(float);
+    struct Candidate { void* p; double us; };
+    std::vector<Candidate> cands;
+    size_t free_b = 0, total_b = 0;
+    const bool search = bytes >= (static_cast<size_t>(1) << 30) && slab_floats >= 65536 && !(debug_flags() & 0x4000000) &&
+                        hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 > bytes * (static_cast<size_t>(chunks) + 1);
+    if (!search) {
+        for (int k = 0; k < chunks; ++k) {
+            void* p = nullptr;
+            if (!b->hip_ok(hipMalloc(&p, bytes), "hipMalloc(rings)")) return false;
+            if (!b->hip_ok(hipMemsetAsync(p, 0, bytes, b->stream), "hipMemsetAsync(rings)")) return false;
+            cands.push_back({p, 0.0});
+        }
+    } else {
+        const size_t max_tries = std::min<size_t>(static_cast<size_t>(chunks) * 2 + 4, free_b / 2 / bytes);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (!b->hip_ok(hipEventCreate(&e0), "hipEventCreate") || !b->hip_ok(hipEventCreate(&e1), "hipEventCreate")) return false;
+        bool ok = true;
+        while (cands.size() < max_tries) {
+            void* c = nullptr;
+            if (hipMalloc(&c, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            cands.push_back({c, 1e30});
+            if (!(ok = b->hip_ok(hipMemsetAsync(c, 0, bytes, b->stream), "hipMemsetAsync(rings)"))) break;
+            for (int r = 0; r < 2; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * r, b->stream);
+            hipEventRecord(e0, b->stream);
+            for (int r = 0; r < 4; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * (2 + r), b->stream);
+            hipEventRecord(e1, b->stream);
+            float ms = 0.0F;
+            if (!(ok = b->hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") && b->hip_ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime"))) break;
+            cands.back().us = ms * 1e3 / 4;
+            b->placement_candidates += 1;
+            if (static_cast<int>(cands.size()) < chunks) continue;
+            std::vector<double> us;
+            for (const auto& c2 : cands) us.push_back(c2.us);
+            std::sort(us.begin(), us.end());
+            // enough candidates of the fastest kind in hand, and a clearly slower kind seen next to them: done
+            if (us[chunks - 1] <= us[0] * 1.04 && us[0] * 1.12 <= us.back()) break;
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        std::stable_sort(cands.begin(), cands.end(), [](const Candidate& x, const Candidate& y) { return x.us < y.us; });
+        if (!ok || static_cast<int>(cands.size()) < chunks) {
+            for (auto& c : cands) (void)hipFree(c.p);
+            return ok ? b->fail("hipMalloc(rings) failed") : false;
+        }
+        for (size_t k = chunks; k < cands.size(); ++k) (void)hipFree(cands[k].p);
+        b->placement_worst_us = std::max(b->placement_worst_us, cands.back().us);
+        cands.resize(chunks);
+        b->placement_best_us = cands.front().us;
+        // (address order within the batch: consecutive instances then sit in consecutive slabs of consecutive chunks)
+        std::sort(cands.begin(), cands.end(), [](const Candidate& x, const Candidate& y) { return x.p < y.p; });
+    }
+    for (auto& c : cands) {
+        b->placed_chunks += 1;
+        b->chunks.push_back(c.p);
+        b->ring_chunks.push_back({static_cast<char*>(c.p), bytes, c.p});
+        out.push_back(static_cast<float*>(c.p));
+    }
+    return true;
+}
+
 // Folds all pending property changes into descriptors, device state and the launch plan: what the
 // reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
 // plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
@@ -397,13 +474,19 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         const int have = static_cast<int>(pool.free_clean.size() + pool.free_dirty.size());
         const int grow = kv.second - have;
         if (grow > 0) {
-            void* chunk = nullptr;
-            const size_t bytes = static_cast<size_t>(grow) * kv.first * sizeof(float);
-            if (!b->hip_ok(hipMalloc(&chunk, bytes), "hipMalloc(rings)")) return false;
-            if (!b->hip_ok(hipMemsetAsync(chunk, 0, bytes, b->stream), "hipMemsetAsync(rings)")) return false;
-            b->chunks.push_back(chunk);
-            // hand the slabs out in address order so that consecutive instances get consecutive slabs
-            for (int k = grow - 1; k >= 0; --k) pool.free_clean.push_back(static_cast<float*>(chunk) + static_cast<size_t>(k) * kv.first);
+            // chunks of at most 4096 slabs (3.6 GiB of reverb delay lines), each placed on its own (place_ring_chunk); the slabs are
+            // handed out in address order within a chunk, chunk after chunk, so that consecutive instances get consecutive slabs
+            constexpr int kChunkSlabs = 4096;
+            std::vector<float*> bases;
+            if (!place_ring_chunks(b, grow / kChunkSlabs, kChunkSlabs, kv.first, bases)) return false;
+            const size_t full = bases.size();
+            if (grow % kChunkSlabs && !place_ring_chunks(b, 1, grow % kChunkSlabs, kv.first, bases)) return false;
+            std::vector<float*> fresh;
+            for (size_t c = 0; c < bases.size(); ++c) {
+                const int count = c < full ? kChunkSlabs : grow % kChunkSlabs;
+                for (int k = 0; k < count; ++k) fresh.push_back(bases[c] + static_cast<size_t>(k) * kv.first);
+            }
+            for (size_t k = fresh.size(); k-- > 0;) pool.free_clean.push_back(fresh[k]);
         }
     }
     bool rings_changed = false;
@@ -525,7 +608,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
 // through the believing builds), 0x400000 ring-light workgroups longest type first instead of in list (type) order, 0x800000 oalsfx_batch_mix_async copies page-locked
 // buffers with kernels instead of the runtime's copy engines, 0x2000000 every reverb listed as proven steady whatever the device said
-// (exercises the fault counter of the FP builds: tests only)
+// (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks
 int g_debug_flags = -1;
 int debug_flags()
 {
@@ -1355,6 +1438,86 @@ int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)
     b->event_pool.push_back(e1);
     if (avg_us) *avg_us = total * 1e3 / repeats;
     return ok ? 1 : 0;
+}
+
+int oalsfx_batch_placement(const oalsfx_batch* b, int* chunks, int* candidates, double* best_us, double* worst_us)
+{
+    if (chunks) *chunks = b->placed_chunks;
+    if (candidates) *candidates = b->placement_candidates;
+    if (best_us) *best_us = b->placement_best_us;
+    if (worst_us) *worst_us = b->placement_worst_us;
+    return 1;
+}
+
+int oalsfx_debug_probe_pointer(void* slabs, int instances, int slab_floats, int repeats, double* avg_us)
+{
+    // the same probe on any device buffer of instances * slab_floats floats (scripts/vram_map.py)
+    if (!slabs || instances <= 0 || repeats <= 0 || slab_floats < 235520) return 0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 2; ++r) oalsfx_hip::launch_stream_pattern(static_cast<float*>(slabs), instances, 1, 256u * r, slab_floats, 0, nullptr);
+    hipEventRecord(e0, nullptr);
+    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_stream_pattern(static_cast<float*>(slabs), instances, 1, 256u * (2 + r), slab_floats, 0, nullptr);
+    hipEventRecord(e1, nullptr);
+    bool ok = hipEventSynchronize(e1) == hipSuccess;
+    float ms = 0.0F;
+    ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (avg_us) *avg_us = ms * 1e3 / repeats;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ok ? 1 : 0;
+}
+
+int oalsfx_debug_probe_rings(oalsfx_batch* b, int repeats, double* avg_us)
+{
+    // the reverb's ring traffic without its arithmetic (k_stream_pattern) on the batch's own delay-line chunk: overwrites the delay lines
+    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr) || b->ring_chunks.empty() || repeats <= 0) return 0;
+    if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    const auto& rc = b->ring_chunks.front();
+    const size_t slab_floats = static_cast<size_t>(ring_floats_for(OALSFX_EAX_REVERB, b->rate));
+    const int instances = static_cast<int>(rc.bytes / (slab_floats * sizeof(float)));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < 4; ++r) oalsfx_hip::launch_stream_pattern(reinterpret_cast<float*>(rc.base), instances, 1, 256u * r, slab_floats, 0, b->stream);
+    hipEventRecord(e0, b->stream);
+    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_stream_pattern(reinterpret_cast<float*>(rc.base), instances, 1, 256u * (4 + r), slab_floats, 0, b->stream);
+    hipEventRecord(e1, b->stream);
+    bool ok = hipEventSynchronize(e1) == hipSuccess;
+    float ms = 0.0F;
+    ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (avg_us) *avg_us = ms * 1e3 / repeats;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ok ? 1 : 0;
+}
+
+int oalsfx_debug_move_rings(oalsfx_batch* b, int keep_old)
+{
+    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
+    if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    const size_t total = static_cast<size_t>(b->n) * b->slots;
+    for (auto& rc : b->ring_chunks) {
+        void* fresh = nullptr;
+        if (!b->hip_ok(hipMalloc(&fresh, rc.bytes), "hipMalloc(rings)")) return 0;
+        if (!b->hip_ok(hipMemcpy(fresh, rc.base, rc.bytes, hipMemcpyDeviceToDevice), "hipMemcpy(rings)")) return 0;
+        const ptrdiff_t delta = static_cast<char*>(fresh) - rc.base;
+        auto inside = [&](float* p) { return reinterpret_cast<char*>(p) >= rc.base && reinterpret_cast<char*>(p) < rc.base + rc.bytes; };
+        auto moved = [&](float* p) { return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + delta); };
+        for (size_t idx = 0; idx < total; ++idx)
+            if (b->h_rings[idx] && inside(b->h_rings[idx])) b->h_rings[idx] = moved(b->h_rings[idx]);
+        for (auto& kv : b->pools) {
+            for (auto& p : kv.second.free_clean) if (inside(p)) p = moved(p);
+            for (auto& p : kv.second.free_dirty) if (inside(p)) p = moved(p);
+        }
+        if (keep_old) {
+            // stays allocated (and counted in `chunks`) so that the next move lands somewhere else again
+        } else {
+            for (auto& c : b->chunks) if (c == rc.alloc) c = nullptr;
+            (void)hipFree(rc.alloc);
+        }
+        b->chunks.push_back(fresh);
+        rc.base = static_cast<char*>(fresh);
+        rc.alloc = fresh;
+    }
+    return b->hip_ok(hipMemcpy(b->d_rings, b->h_rings.data(), total * sizeof(float*), hipMemcpyHostToDevice), "hipMemcpy(ring table)") ? 1 : 0;
 }
 
 unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int slot)

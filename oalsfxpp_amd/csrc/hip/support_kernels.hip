@@ -386,6 +386,45 @@ __global__ __launch_bounds__(256) void k_stream_pattern(float* slabs, int instan
     }
 }
 
+// ---- placement probe (batch.cpp: place_ring_chunk): the shape of the reverb kernel's ring traffic -- per slab 24 read streams at
+// unaligned positions and 24 aligned write streams, 256 frames, one wavefront per slab, the next tile's reads requested ahead -- on a
+// freshly zeroed chunk.  It writes the sums of what it read, i.e. zeros: the chunk stays zero-filled.  Where a chunk lands in the
+// card's memory moves this traffic's rate by 15 % (profiles/README.md, vram map); the runtime keeps the fastest of a few candidates.
+__global__ __launch_bounds__(256) void k_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0)
+{
+    const int lane = threadIdx.x & 63;
+    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (inst >= instances) return;
+    float* slab = slabs + static_cast<size_t>(inst) * slab_floats;
+    const unsigned span = static_cast<unsigned>(slab_floats / 48) & ~63u; // floats per stream region
+    const unsigned wrap = span - 64u;
+    float cur[24];
+    auto issue = [&](int step, float* dst) {
+#pragma unroll
+        for (int s = 0; s < 24; ++s) dst[s] = slab[s * span + (pos0 + step * 64 + lane + 13u + 37u * s) % wrap];
+    };
+    issue(0, cur);
+    for (int step = 0; step < 4; ++step) {
+        float nxt[24];
+        if (step + 1 < 4) issue(step + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        float acc = cur[0];
+#pragma unroll
+        for (int s = 1; s < 24; ++s) acc += cur[s];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) slab[(24 + s) * span + ((pos0 + step * 64) % wrap & ~63u) + lane] = acc;
+        if (step + 1 < 4) {
+#pragma unroll
+            for (int s = 0; s < 24; ++s) cur[s] = nxt[s];
+        }
+    }
+}
+
+void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_ring_probe, dim3((instances + 3) / 4), dim3(256), 0, stream, slabs, instances, slab_floats, pos0);
+}
+
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream)
 {
     const dim3 grid((instances + 3) / 4), block(256);

@@ -48,10 +48,14 @@ SIGNATURES = {
     "oalsfx_batch_event_overhead": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_batch_kernel_timing_samples": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]),
     "oalsfx_batch_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "oalsfx_batch_placement": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "oalsfx_debug_set_flags": (None, [C.c_int]),
     "oalsfx_debug_ring_address": (C.c_ulonglong, [C.c_void_p, C.c_int, C.c_int]),
+    "oalsfx_debug_move_rings": (C.c_int, [C.c_void_p, C.c_int]),
+    "oalsfx_debug_probe_rings": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "oalsfx_debug_probe_pointer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_debug_hbm_sweep": (C.c_int, [C.c_int, C.c_ulonglong, C.c_int, C.c_int]),
     "oalsfx_debug_stream_pattern": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "oalsfx_host_effect_defaults": (None, [C.c_int, C.POINTER(desc.Effect)]),

@@ -81,17 +81,27 @@ class Lib:
 order = (0, 1, 1, 0)
 libs = [Lib(paths[w]) for w in order]
 rounds = {0: [], 1: []}
+per_batch = {k: [] for k in range(4)}
 for rnd in range(12):
     for k in (0, 1, 2, 3) if rnd % 2 == 0 else (3, 2, 1, 0):
         libs[k].run(16 if F <= 512 else 4)
         libs[k].sync()
-        rounds[order[k]].append(libs[k].timed(64 if F <= 512 else 16))
+        t = libs[k].timed(64 if F <= 512 else 16)
+        rounds[order[k]].append(t)
+        per_batch[k].append(t)
 pair = C.c_double(0.0)
 libs[1].so.oalsfx_batch_event_overhead(libs[1].h, 200, C.byref(pair))
 for which in (0, 1):
     v = sorted(rounds[which])
     print(f"{os.path.basename(paths[which]):36s} median of {len(v)} rounds x 64 launches (two batches): {v[len(v) // 2] - pair.value:6.2f} us   "
           f"(min {v[0] - pair.value:.2f}, max {v[-1] - pair.value:.2f}; empty event pair {pair.value:.2f} us taken off)")
+print("per batch, in creation order: " + ", ".join(f"{os.path.basename(paths[order[k]])[12:-3] or 'product'} {sorted(per_batch[k])[len(per_batch[k]) // 2] - pair.value:.2f}" for k in range(4)))
+for k in range(4):
+    so = libs[k].so
+    if hasattr(so, "oalsfx_debug_ring_address"):
+        so.oalsfx_debug_ring_address.restype = C.c_ulonglong
+        so.oalsfx_debug_ring_address.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        print(f"  batch {k}: rings at {so.oalsfx_debug_ring_address(libs[k].h, 0, 0):#x}, src {libs[k].src[0].data_ptr():#x} {libs[k].src[1].data_ptr():#x}, dst {libs[k].dst.data_ptr():#x}")
 a, b = sorted(rounds[0])[len(rounds[0]) // 2] - pair.value, sorted(rounds[1])[len(rounds[1]) // 2] - pair.value
 print(f"b / a = {b / a:.4f}")
 for l in libs:
