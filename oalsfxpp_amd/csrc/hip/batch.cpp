@@ -300,7 +300,7 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
     struct Candidate { void* p; double us; };
     std::vector<Candidate> cands;
     size_t free_b = 0, total_b = 0;
-    const bool search = bytes >= (static_cast<size_t>(1) << 30) && slab_floats >= 65536 && !(debug_flags() & 0x4000000) &&
+    const bool search = bytes >= (static_cast<size_t>(3) << 28) && slab_floats >= 65536 && !(debug_flags() & 0x4000000) &&
                         hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 > bytes * (static_cast<size_t>(chunks) + 1);
     if (!search) {
         for (int k = 0; k < chunks; ++k) {
@@ -310,7 +310,8 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
             cands.push_back({p, 0.0});
         }
     } else {
-        const size_t max_tries = std::min<size_t>(static_cast<size_t>(chunks) * 2 + 4, free_b / 2 / bytes);
+        const size_t max_tries = std::min<size_t>({static_cast<size_t>(chunks) * 6 + 8, free_b / 2 / bytes, static_cast<size_t>(96)});
+        const int waves_per_slab = std::max(1, 4096 / count); // a full load (4096 wavefronts) whatever the chunk's size
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (!b->hip_ok(hipEventCreate(&e0), "hipEventCreate") || !b->hip_ok(hipEventCreate(&e1), "hipEventCreate")) return false;
         bool ok = true;
@@ -319,9 +320,9 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
             if (hipMalloc(&c, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
             cands.push_back({c, 1e30});
             if (!(ok = b->hip_ok(hipMemsetAsync(c, 0, bytes, b->stream), "hipMemsetAsync(rings)"))) break;
-            for (int r = 0; r < 2; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * r, b->stream);
+            for (int r = 0; r < 2; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * r, waves_per_slab, b->stream);
             hipEventRecord(e0, b->stream);
-            for (int r = 0; r < 4; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * (2 + r), b->stream);
+            for (int r = 0; r < 4; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * (2 + r), waves_per_slab, b->stream);
             hipEventRecord(e1, b->stream);
             float ms = 0.0F;
             if (!(ok = b->hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") && b->hip_ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime"))) break;
@@ -474,9 +475,9 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         const int have = static_cast<int>(pool.free_clean.size() + pool.free_dirty.size());
         const int grow = kv.second - have;
         if (grow > 0) {
-            // chunks of at most 4096 slabs (3.6 GiB of reverb delay lines), each placed on its own (place_ring_chunk); the slabs are
+            // chunks of at most 1024 slabs (0.9 GiB of reverb delay lines), each placed on its own (place_ring_chunk); the slabs are
             // handed out in address order within a chunk, chunk after chunk, so that consecutive instances get consecutive slabs
-            constexpr int kChunkSlabs = 4096;
+            constexpr int kChunkSlabs = 1024; // 0.9 GiB of reverb delay lines
             std::vector<float*> bases;
             if (!place_ring_chunks(b, grow / kChunkSlabs, kChunkSlabs, kv.first, bases)) return false;
             const size_t full = bases.size();
@@ -1451,13 +1452,14 @@ int oalsfx_batch_placement(const oalsfx_batch* b, int* chunks, int* candidates, 
 
 int oalsfx_debug_probe_pointer(void* slabs, int instances, int slab_floats, int repeats, double* avg_us)
 {
-    // the same probe on any device buffer of instances * slab_floats floats (scripts/vram_map.py)
-    if (!slabs || instances <= 0 || repeats <= 0 || slab_floats < 235520) return 0;
+    // the placement probe on any device buffer of instances * slab_floats floats, always 4096 wavefronts (scripts/vram_map.py)
+    if (!slabs || instances <= 0 || repeats <= 0 || slab_floats < 65536) return 0;
+    const int wps = std::max(1, 4096 / instances);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int r = 0; r < 2; ++r) oalsfx_hip::launch_stream_pattern(static_cast<float*>(slabs), instances, 1, 256u * r, slab_floats, 0, nullptr);
+    for (int r = 0; r < 2; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(slabs), instances, slab_floats, 256u * r, wps, nullptr);
     hipEventRecord(e0, nullptr);
-    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_stream_pattern(static_cast<float*>(slabs), instances, 1, 256u * (2 + r), slab_floats, 0, nullptr);
+    for (int r = 0; r < repeats; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(slabs), instances, slab_floats, 256u * (2 + r), wps, nullptr);
     hipEventRecord(e1, nullptr);
     bool ok = hipEventSynchronize(e1) == hipSuccess;
     float ms = 0.0F;

@@ -122,7 +122,7 @@ void launch_null(hipStream_t stream);
 // dst[0 .. floats) = src[0 .. floats), either of them possibly page-locked host memory mapped into the device's address space
 void launch_copy_floats(float* dst, const float* src, size_t floats, hipStream_t stream);
 void launch_fill_synthetic(float* dst, int instances, int floats_per_instance, unsigned buffer_index, hipStream_t stream);
-void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, hipStream_t stream);
+void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, int waves_per_slab, hipStream_t stream);
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream);
 void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 

@@ -390,11 +390,13 @@ __global__ __launch_bounds__(256) void k_stream_pattern(float* slabs, int instan
 // unaligned positions and 24 aligned write streams, 256 frames, one wavefront per slab, the next tile's reads requested ahead -- on a
 // freshly zeroed chunk.  It writes the sums of what it read, i.e. zeros: the chunk stays zero-filled.  Where a chunk lands in the
 // card's memory moves this traffic's rate by 15 % (profiles/README.md, vram map); the runtime keeps the fastest of a few candidates.
-__global__ __launch_bounds__(256) void k_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0)
+__global__ __launch_bounds__(256) void k_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, int waves_per_slab)
 {
     const int lane = threadIdx.x & 63;
-    const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int inst = wave / waves_per_slab; // several wavefronts per slab (at different positions) make a small chunk carry a full load
     if (inst >= instances) return;
+    pos0 += static_cast<unsigned>(wave % waves_per_slab) * 1088u;
     float* slab = slabs + static_cast<size_t>(inst) * slab_floats;
     const unsigned span = static_cast<unsigned>(slab_floats / 48) & ~63u; // floats per stream region
     const unsigned wrap = span - 64u;
@@ -420,9 +422,10 @@ __global__ __launch_bounds__(256) void k_ring_probe(float* slabs, int instances,
     }
 }
 
-void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, hipStream_t stream)
+void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned pos0, int waves_per_slab, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_ring_probe, dim3((instances + 3) / 4), dim3(256), 0, stream, slabs, instances, slab_floats, pos0);
+    const int waves = instances * waves_per_slab;
+    hipLaunchKernelGGL(k_ring_probe, dim3((waves + 3) / 4), dim3(256), 0, stream, slabs, instances, slab_floats, pos0, waves_per_slab);
 }
 
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream)

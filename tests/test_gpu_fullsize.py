@@ -163,3 +163,30 @@ def test_rates_above_192_khz(rate):
         for i in range(n):
             d = shadows[i].compare_state()
             assert not d, f"{rate} Hz, instance {i}: " + "; ".join(d[:4])
+
+
+def test_delay_line_placement_search_leaves_the_chunk_zero_filled():
+    """Chunks of 1 GiB and more are chosen among probed candidates.  The probe runs the reverb's traffic pattern over the whole
+    chunk; fresh delay lines must still be all zero afterwards, which the first buffers of fresh instances show (they read far back
+    into their rings), here for the first, a middle and the last slab of the chunk."""
+    n = 1300  # 1.14 GiB of reverb delay lines: one searched chunk
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect(i % 113) for i in range(n)])
+        b.apply_changes()
+        sample = [0, 1, 649, 650, n - 2, n - 1]
+        shadows = {i: OracleShadow(b, i) for i in sample}
+        for k in range(3):
+            x = np.stack([orc.synth(5000 + i, k, 512).reshape(256, 2) for i in range(n)])
+            y = b.mix(x)
+            for i in sample:
+                ok, nbad = same_bits(y[i], shadows[i].mix(x[i]))
+                assert ok, f"instance {i} buffer {k}: {nbad} samples differ"
+        chunks, candidates, kept_us, slowest_us = b.placement()
+        assert chunks == 1 and candidates >= 1 and 0.0 < kept_us <= slowest_us
+        for i in sample:
+            assert not shadows[i].compare_state(), f"instance {i}: state differs"
+    with Batch(64, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        b.mix(np.zeros((64, 64, 2), dtype=np.float32))
+        assert b.placement()[:2] == (1, 0)   # small chunks are taken as they come
