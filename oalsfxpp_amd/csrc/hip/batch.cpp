@@ -291,7 +291,7 @@ void advance_settling(oalsfx_batch* b, int frames)
 // (scripts/move_rings_probe.py).  So for chunks of 1 GiB and more the runtime does not take the first allocations it is given: it
 // allocates candidates (all held, or the driver would hand the same pages out again), times the probe on each (k_ring_probe, which
 // leaves the memory zero-filled), stops once it holds enough of the fastest kind and has seen a clearly slower one (or after
-// 2 * chunks + 4 candidates, or half the free memory), keeps the fastest and frees the rest.  A few hundred milliseconds, once per
+// 96 candidates -- four times the chunks wanted if that is more --, or half the free memory), keeps the fastest and frees the rest.  A few hundred milliseconds, once per
 // batch.  OALSFX_DEBUG_FLAGS 0x4000000 switches the search off.
 bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_floats, std::vector<float*>& out)
 {
@@ -310,7 +310,7 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
             cands.push_back({p, 0.0});
         }
     } else {
-        const size_t max_tries = std::min<size_t>({static_cast<size_t>(chunks) * 6 + 8, free_b / 2 / bytes, static_cast<size_t>(96)});
+        const size_t max_tries = std::min<size_t>(std::max<size_t>(96, static_cast<size_t>(chunks) * 4), free_b / 2 / bytes);
         const int waves_per_slab = std::max(1, 4096 / count); // a full load (4096 wavefronts) whatever the chunk's size
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (!b->hip_ok(hipEventCreate(&e0), "hipEventCreate") || !b->hip_ok(hipEventCreate(&e1), "hipEventCreate")) return false;
@@ -328,7 +328,7 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
             if (!(ok = b->hip_ok(hipEventSynchronize(e1), "hipEventSynchronize") && b->hip_ok(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime"))) break;
             cands.back().us = ms * 1e3 / 4;
             b->placement_candidates += 1;
-            if (static_cast<int>(cands.size()) < chunks) continue;
+            if (cands.size() < std::min<size_t>(max_tries, static_cast<size_t>(chunks) * 3 + 4)) continue; // a fair sample first
             std::vector<double> us;
             for (const auto& c2 : cands) us.push_back(c2.us);
             std::sort(us.begin(), us.end());
