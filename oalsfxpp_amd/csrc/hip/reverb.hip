@@ -682,12 +682,6 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts (top and end of S1, S3): a wavefront
             // that issues all 24 in one go sits in the issue queue while its siblings and its own arithmetic wait
             if (has_a && it > 0) issue_taps_a(t4 + 256u); // (the prologue issued tile 0's)
-#ifdef OALSFX_TAPS_EARLY
-            if (has_a) issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2);
-#if OALSFX_TAPS_EARLY == 2
-            if (has_a) issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
-#endif
-#endif
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
         }
         // ---------------- S1, late half: P3(tb): main delay write, early reflections, late taps, T60 first feed-forward ----------------
@@ -858,17 +852,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 ch[coop::LPX1] = rowI(0, lane)[4 + La - 2]; ch[coop::LPX0] = rowI(0, lane)[4 + La - 1]; // La == 1: [3] is the old newest sample
             }
         }
-#ifndef OALSFX_TAPS_EARLY
         if (go && has_a) {
+            // (all of a tile's requests at the top of S1, or the late all-pass group here instead of in S3: measured, no faster)
             issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2); // on their way while the chain phases run
             __builtin_amdgcn_sched_barrier(0);
         }
-#elif OALSFX_TAPS_EARLY == 3
-        if (go && has_a) {
-            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
         stamp();
         lds_barrier();
         stamp();
@@ -895,12 +883,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         lds_barrier();
         stamp();
         // ---------------- S3: P2(ta), feed-forward half of the second shelf; P4(tb), second T60 feed-forward ----------------
-#if !defined(OALSFX_TAPS_EARLY) || OALSFX_TAPS_EARLY == 1
         if (go && has_a) {
             issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
         if (any_eax) {
             if (go && eax && has_a) {
                 const v4f bq = *reinterpret_cast<const v4f*>(utf + ut::HPB);
@@ -1075,11 +1061,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-#ifndef OALSFX_FP_OCCUPANCY
-#define OALSFX_FP_OCCUPANCY 4
-#endif
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false>
-__global__ __launch_bounds__(64 * NW, (FP && !MD) ? OALSFX_FP_OCCUPANCY : 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
     reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
