@@ -305,9 +305,13 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
     if (!search) {
         for (int k = 0; k < chunks; ++k) {
             void* p = nullptr;
-            if (!b->hip_ok(hipMalloc(&p, bytes), "hipMalloc(rings)")) return false;
-            if (!b->hip_ok(hipMemsetAsync(p, 0, bytes, b->stream), "hipMemsetAsync(rings)")) return false;
-            cands.push_back({p, 0.0});
+            bool ok = b->hip_ok(hipMalloc(&p, bytes), "hipMalloc(rings)");
+            if (ok) cands.push_back({p, 0.0});
+            ok = ok && b->hip_ok(hipMemsetAsync(p, 0, bytes, b->stream), "hipMemsetAsync(rings)");
+            if (!ok) {
+                for (auto& c : cands) (void)hipFree(c.p);
+                return false;
+            }
         }
     } else {
         const size_t max_tries = std::min<size_t>(std::max<size_t>(96, static_cast<size_t>(chunks) * 4), free_b / 2 / bytes);
