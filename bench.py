@@ -299,6 +299,10 @@ def main():
     src, dst = resident_inputs(batch, n, rank, n_in)
     for k in range(args.warmup):
         batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+        if k < 2:
+            # fresh reverbs cross-fade through their first buffer; once the device has reported them settled (the read-back is looked at
+            # by a synchronising call) they are listed for the steady-state builds: let that happen inside the warm-up, however short
+            batch.synchronize()
 
     # every 8th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
     # be part of `value`
