@@ -6,8 +6,10 @@ namespace oalsfx_hip {
 // One wavefront per listed instance, any mix of the ring-light effect types, for `slot_count` consecutive slots starting at
 // `slot`: the host fuses runs of slots that hold no reverb at all, so that an instance's chorus -> flanger -> echo chain
 // is one launch (the slots still accumulate in order, through mixbuf, by the same wavefront).
+// 4096 instances are 1024 workgroups, four per compute unit: one round of the chip only while a wavefront keeps to 128 registers
+// (at 133 the same grid took a second round and every effect type was 1.5 - 1.7 times slower), hence the occupancy bound.
 template <int CH>
-__global__ __launch_bounds__(256) void k_wave_effects(KernelCtx ctx, int slot, int slot_count, const int* __restrict__ list, int count, WaveSegments seg,
+__global__ __launch_bounds__(256, CH == 8 ? 2 : 4) void k_wave_effects(KernelCtx ctx, int slot, int slot_count, const int* __restrict__ list, int count, WaveSegments seg,
                                                       int flags)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[4][wfx::kLdsFloats];

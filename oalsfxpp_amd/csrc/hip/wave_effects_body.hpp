@@ -773,8 +773,6 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     };
     stamp();
     Fx fx;
-    fx.init(I);
-    stamp();
 
     // the inputs of a tile (source frame, filtered send input, accumulated mix of the earlier slots) do not depend on the effect:
     // they are requested one tile ahead, so that their latency hides behind the body of the current tile
@@ -830,7 +828,9 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     int held_pos = 0, held_L = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) held[c] = 0.0F;
-    request(0);
+    request(0);   // ahead of the effect's own start-up loads: one round trip for both
+    fx.init(I);
+    stamp();
     for (int base = 0; base < frames + (kLag ? 64 : 0); base += 64) {
         const int L = base < frames ? min(64, frames - base) : 0;
         const bool act = lane < L;

@@ -2,7 +2,7 @@
 """Same box, same process: two builds of liboalsfx_hip.so timed alternately on the headline workload (one batch per build, resident
 together), many rounds; per round the average HIP-event duration of the steady-state reverb launch, then the median over rounds.
 
-    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets] [frames per call]
+    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets | type:<NAME of a ring-light type, e.g. type:CHORUS>] [frames per call]
 
 Raw ctypes on both libraries (two builds cannot share the Python mirror's single handle)."""
 import ctypes as C
@@ -19,6 +19,7 @@ paths = [os.path.abspath(p) for p in sys.argv[1:3]]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 workload = sys.argv[4] if len(sys.argv) > 4 else "eax"
 F = int(sys.argv[5]) if len(sys.argv) > 5 else 256   # frames per call
+TYPE = getattr(desc, workload[5:]) if workload.startswith("type:") else desc.EAX_REVERB
 
 
 class Lib:
@@ -45,7 +46,7 @@ class Lib:
                 so.oalsfx_host_preset(i % 113, C.byref(arr[i].props.reverb))
             assert so.oalsfx_batch_set_effect(self.h, 0, n, 0, arr, C.sizeof(desc.Effect))
         else:
-            assert so.oalsfx_batch_set_effect_type(self.h, 0, n, 0, desc.EAX_REVERB)
+            assert so.oalsfx_batch_set_effect_type(self.h, 0, n, 0, TYPE)
         assert so.oalsfx_batch_apply_changes(self.h, 0, n)
         self.src = [torch.empty(n * F * 2, dtype=torch.float32, device="cuda") for _ in range(4)]
         self.dst = torch.empty(n * F * 2, dtype=torch.float32, device="cuda")
@@ -69,7 +70,7 @@ class Lib:
         self.run(k)
         self.sync()
         cnt, ms = C.c_int(0), C.c_double(0.0)
-        self.so.oalsfx_batch_kernel_timing_read(self.h, desc.EAX_REVERB, C.byref(cnt), C.byref(ms))
+        self.so.oalsfx_batch_kernel_timing_read(self.h, TYPE, C.byref(cnt), C.byref(ms))
         g, gms = C.c_int(0), C.c_double(0.0)
         self.so.oalsfx_batch_kernel_timing_read(self.h, desc.REVERB + 16, C.byref(g), C.byref(gms))
         self.so.oalsfx_batch_kernel_timing(self.h, 0)
