@@ -42,9 +42,45 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Feedback half of a biquad over entries [lo, hi) of a row that holds the feed-forward sums; outputs replace them.
-// y = (u - a1*y1) - a2*y2 (reference FilterState::process, src/oalsfxpp.cpp:1009-1014).  row[lo + 3], row[lo + 2] hold
-// the two outputs before `lo`.
+// Feedback half of a biquad over a whole tile: entries [0, N) of a row that holds the feed-forward sums; outputs replace them.
+// y = (u - a1*y1) - a2*y2 (reference FilterState::process, src/oalsfxpp.cpp:1009-1014).  row[3], row[2] hold the two outputs
+// before the tile.  Every trip count is known to the compiler (chain_biquad below takes the ragged cases).
+template <int N>
+__device__ __forceinline__ void chain_biquad_whole(float* row, float a1, float a2)
+{
+    static_assert(N % 32 == 0, "two blocks of sixteen per round");
+    float y1 = row[3], y2 = row[2];
+    auto step4 = [&](float4& v) {
+        v.x = (v.x - (a1 * y1)) - (a2 * y2);
+        v.y = (v.y - (a1 * v.x)) - (a2 * y1);
+        v.z = (v.z - (a1 * v.y)) - (a2 * v.x);
+        v.w = (v.w - (a1 * v.z)) - (a2 * v.y);
+        y2 = v.z;
+        y1 = v.w;
+    };
+    // Two register blocks of sixteen samples, A and B, taking turns.  The order of the LDS traffic is chosen for the one place where
+    // the compiler waits for all of it, the loop's back edge: what is outstanding there was issued sixteen steps earlier.
+    float4* r4 = reinterpret_cast<float4*>(row + 4);
+    float4 a0 = r4[0], a1v = r4[1], a2v = r4[2], a3 = r4[3];
+    float4 b0 = r4[4], b1 = r4[5], b2 = r4[6], b3 = r4[7];
+    step4(a0); step4(a1v); step4(a2v); step4(a3);
+    r4[0] = a0; r4[1] = a1v; r4[2] = a2v; r4[3] = a3;
+    a0 = r4[8]; a1v = r4[9]; a2v = r4[10]; a3 = r4[11];
+    step4(b0); step4(b1); step4(b2); step4(b3);
+#pragma unroll 1
+    for (int q = 8; q < N / 4; q += 8) {
+        r4[q - 4] = b0; r4[q - 3] = b1; r4[q - 2] = b2; r4[q - 1] = b3;
+        b0 = r4[q + 4]; b1 = r4[q + 5]; b2 = r4[q + 6]; b3 = r4[q + 7];
+        step4(a0); step4(a1v); step4(a2v); step4(a3);
+        r4[q + 0] = a0; r4[q + 1] = a1v; r4[q + 2] = a2v; r4[q + 3] = a3;
+        // (the last round requests the sixteen floats behind the tile: inside the wavefront's LDS for every caller, never used)
+        a0 = r4[q + 8]; a1v = r4[q + 9]; a2v = r4[q + 10]; a3 = r4[q + 11];
+        step4(b0); step4(b1); step4(b2); step4(b3);
+    }
+    r4[N / 4 - 4] = b0; r4[N / 4 - 3] = b1; r4[N / 4 - 2] = b2; r4[N / 4 - 1] = b3;
+}
+
+// The same over entries [lo, hi) of the row; row[lo + 3], row[lo + 2] hold the two outputs before `lo`.
 __device__ __forceinline__ void chain_biquad(float* row, int lo, int hi, float a1, float a2)
 {
     float y1 = row[4 + lo - 1], y2 = row[4 + lo - 2];
@@ -681,7 +717,9 @@ struct DistortionW {
         // sums the call before left in its row); the same code on two lanes
         chain_phase(I, 2, [n, np](float* lds, int line) {
             float* row = lds + (line ? 2 * kArr : 0);
-            chain_biquad(row, 0, line ? np : n, row[0], row[1]);
+            const int cnt = line ? np : n;
+            if (cnt == 256) chain_biquad_whole<256>(row, row[0], row[1]);
+            else chain_biquad(row, 0, cnt, row[0], row[1]);
         });
         if (Lp > 0) {
             const float kept = bp[4 + 4 * lane];

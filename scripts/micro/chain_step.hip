@@ -70,6 +70,20 @@ __global__ __launch_bounds__(256) void k(float* out, long long* ticks, unsigned*
                     step4(n0, y1, y2, a1, a2); step4(n1, y1, y2, a1, a2); step4(n2, y1, y2, a1, a2); step4(n3, y1, y2, a1, a2);
                     r4[q + 4] = n0; r4[q + 5] = n1; r4[q + 6] = n2; r4[q + 7] = n3;
                 }
+            } else if (V == 6 || V == 7) {
+                // variant 2 without its stores (6) or without its loads (7): what does each cost?
+                float4* r4 = reinterpret_cast<float4*>(row + 4);
+                float4 c0 = r4[0], c1 = r4[1], c2 = r4[2], c3 = r4[3];
+                for (int i = 0; i + 32 <= kN; i += 32) {
+                    const int q = i >> 2;
+                    float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+                    if (V == 6) { n0 = r4[q + 4]; n1 = r4[q + 5]; n2 = r4[q + 6]; n3 = r4[q + 7]; }
+                    step4(c0, y1, y2, a1, a2); step4(c1, y1, y2, a1, a2); step4(c2, y1, y2, a1, a2); step4(c3, y1, y2, a1, a2);
+                    if (V == 7) { r4[q + 0] = c0; r4[q + 1] = c1; r4[q + 2] = c2; r4[q + 3] = c3; }
+                    if (V == 6 && i + 64 <= kN) { c0 = r4[q + 8]; c1 = r4[q + 9]; c2 = r4[q + 10]; c3 = r4[q + 11]; }
+                    step4(n0, y1, y2, a1, a2); step4(n1, y1, y2, a1, a2); step4(n2, y1, y2, a1, a2); step4(n3, y1, y2, a1, a2);
+                    if (V == 7) { r4[q + 4] = n0; r4[q + 5] = n1; r4[q + 6] = n2; r4[q + 7] = n3; c0 = n3; c1 = n2; c2 = n1; c3 = n0; }
+                }
             } else if (V == 4 || V == 5) {
                 // four samples at a time, one request ahead (reverb.hip biquad_chain), unrolled 8 or 16 times
                 float4* r4 = reinterpret_cast<float4*>(row + 4);
@@ -147,8 +161,10 @@ int main()
     for (int grid : {256, 1024})
         for (int lanes : {8, 16, 64}) {
             if (run<0>("registers only", grid, lanes, 0)) return 1;
-            if (run<1>("16-sample blocks, moves (product)", grid, lanes, 0)) return 1;
+            if (run<1>("16-sample blocks, moves (round 1)", grid, lanes, 0)) return 1;
             if (run<2>("16-sample blocks, alternating", grid, lanes, 0)) return 1;
+            if (run<6>("  ... without the stores", grid, lanes, 0)) return 1;
+            if (run<7>("  ... without the loads", grid, lanes, 0)) return 1;
             if (run<3>("32-sample blocks, alternating", grid, lanes, 0)) return 1;
             if (run<4>("4-sample blocks, unrolled 8", grid, lanes, 0)) return 1;
             if (run<5>("4-sample blocks, unrolled 16", grid, lanes, 0)) return 1;
