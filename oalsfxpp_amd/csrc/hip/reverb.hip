@@ -864,18 +864,21 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (duty == ((NW == 2) ? 0 : 0 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_a) {
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
-            crowI2[3] = y1; crowI2[2] = y2; // history prefix for the second shelf's feed-forward half
+            const float h1 = y1, h2 = y2;
             biquad_chain(crowI1, crowI2, La, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            // history prefix for the second shelf's feed-forward half (behind the recurrence: its first requests do not wait for these stores)
+            crowI2[3] = h1; crowI2[2] = h2;
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
             __builtin_amdgcn_s_setprio(0);
         }
         if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O1];
-            crowL2[3] = prev; // the second section's feed-forward half needs o1[-1]
+            const float before = prev;
 #ifndef OALSFX_ABLATE_T60_CHAINS // timing experiment (scripts/README: upper bound of what a parallel prefix of these sections could save; results wrong)
             first_order_chain(crowL1, crowL2, 0, Lb, cdat[coop::T_L2], 1.0F, false, prev);
 #endif
+            crowL2[3] = before; // the second section's feed-forward half needs o1[-1]
             cdat[coop::T60O1] = prev;
             __builtin_amdgcn_s_setprio(0);
         }

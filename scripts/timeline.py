@@ -18,9 +18,11 @@ names = ["S1", "S2", "S3", "S4", "S5"]
 work = {n: [] for n in names}
 wait = {n: [] for n in names[:-1]}
 it_total, kernel_total, prologue, epilogue, first_it, last_it = [], [], [], [], [], []
+duty = {"S2": [], "S4": []}   # the two longest of a workgroup's four wavefronts in a chain step: the ones that ran the recurrences
 for wg in raw:
     if wg[0, 0] == 0:
         continue
+    per_wave = {"S2": [], "S4": []}
     for w in wg:
         n = int(np.count_nonzero(w))
         ts = w[:n].astype(np.int64)
@@ -37,11 +39,19 @@ for wg in raw:
                 if 0 < t < its - 1:
                     work[names[k]].append(s[2 * k] - prev)
                     wait[names[k]].append(s[2 * k + 1] - s[2 * k])
+                    if names[k] in per_wave:
+                        per_wave[names[k]].append((t, s[2 * k] - prev))
                 prev = s[2 * k + 1]
             if 0 < t < its - 1:
                 work["S5"].append(s[8] - prev)
             prev = s[8]
             (first_it if t == 0 else last_it if t == its - 1 else it_total).append(prev - start)
+    for name, v in per_wave.items():
+        by_it = {}
+        for t, d in v:
+            by_it.setdefault(t, []).append(d)
+        for t, ds in by_it.items():
+            duty[name] += sorted(ds)[-2:]
 scale = (kernel_us / float(np.mean(kernel_total))) if kernel_us else 1.0
 unit = "us" if kernel_us else "ticks"
 us = lambda v: float(np.mean(v)) * scale
@@ -55,3 +65,6 @@ for n in names:
     tw += w; tb += b
     print(f"  {n}: work {w:6.2f}   barrier wait {b:6.2f}   (max work {np.max(work[n]) * scale:6.2f})")
 print(f"  middle iterations: work {tw:6.2f}, barrier wait {tb:6.2f} {unit}")
+for name in ("S2", "S4"):
+    if duty[name]:
+        print(f"  {name}: the two wavefronts that ran the recurrences: {us(duty[name]):.2f} {unit} on average ({64 * 1000 * us(duty[name]) / 64 / 64:.1f} ns a step of 64)" if kernel_us else f"  {name}: duty wavefronts {us(duty[name]):.0f} ticks")
