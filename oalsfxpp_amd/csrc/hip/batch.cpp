@@ -662,15 +662,18 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     KernelCtx c = ctx;
     c.progress = hand_over ? b->d_progress : nullptr;
     c.list_first = proven ? b->fast_first[slot] : -1;
+    // the proven-steady instances lead the steady region of the list: the general kernel need not look at them
+    const int lead = hand_over && !(debug_flags() & 0x200000) ? std::max(0, std::min(count, b->steady_offset[slot] + b->fast_count[slot] - offset)) : 0;
+    c.no_follow_up = lead;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
         const char* name = oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0,
                                                             b->modulated[slot], b->n_short[slot] > 0, proven, stream);
         if (name) b->last_steady_kernel = name;
     }
-    if (hand_over) {
+    if (hand_over && count > lead) {
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
-        oalsfx_hip::launch_reverb_general(c, slot, list, count, flags, stream);
+        oalsfx_hip::launch_reverb_general(c, slot, list + lead, count - lead, flags, stream);
     }
 }
 
@@ -817,6 +820,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.exact = b->d_exact;
     ctx.fault = b->d_fault;
     ctx.list_first = -1;
+    ctx.no_follow_up = 0;
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;

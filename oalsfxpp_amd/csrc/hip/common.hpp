@@ -46,6 +46,8 @@ struct KernelCtx {
     unsigned* fault;                    // one counter: instances an FP build found not to be steady after all (a broken host invariant: reported
                                         // by the next synchronising call, never silently)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
+    int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
+                              // will not be run on them; one that is not steady after all is counted in `fault`
 };
 
 // The packed per-(instance, slot) start record of the proven-steady reverb kernel: the LDS table image, the filter histories and the

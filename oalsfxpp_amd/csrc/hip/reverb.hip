@@ -1055,6 +1055,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if (MC || ctx.progress != nullptr) {
         // the general kernel follows on the same list: tell it how far this instance got
         if (valid && lane == 0) ctx.progress[sidx] = go ? frames : 0;
+        if (valid && lane == 0 && !go && w < ctx.no_follow_up && ctx.fault) __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else if constexpr (!MC) {
         if (valid && !go) {
             KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
@@ -1743,7 +1744,9 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
     if (c.channels > 2) {
         // multichannel: the most general build only; the caller launches the general kernel on the same list right after
         if (ragged) OALSFX_STEADY(8, 4, false, true, true, true, true, false);
-        OALSFX_STEADY(8, 4, false, true, true, true, false, false);
+        if (short_taps || modulated) OALSFX_STEADY(8, 4, false, true, true, true, false, false);
+        if (close_taps) OALSFX_STEADY(8, 4, false, true, false, false, false, false);
+        OALSFX_STEADY(8, 4, false, false, false, false, false, false);
     }
     if (ragged) {
         if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, true, false);

@@ -173,18 +173,47 @@ def test_proven_path_without_waiting_for_the_stream():
             assert not s.compare_state(), f"instance {i}: state differs"
 
 
-def test_a_broken_host_invariant_is_reported_not_hidden():
-    """The FP builds have no general path to fall back to.  If the host ever listed an instance that is not steady (here forced with a
-    test switch: fresh instances, still cross-fading), the kernel counts it and the next synchronising call fails loudly."""
+@pytest.mark.parametrize("fmt", [desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_7POINT1])
+def test_multichannel_proven_instances_skip_the_general_follow_up(fmt):
+    """More than two channels: the steady-state kernel hands what it does not take to the general kernel launched right behind it
+    on the same list.  Proven instances lead that list and the follow-up starts behind them; a change takes an instance back
+    into the followed-up part until the device confirms it again.  Plain, close-tap, modulated and short-tap presets, so that
+    every multichannel build runs; whole-tile and ragged calls."""
+    for presets in ([0, 4, 12, 0, 4], [2, 0, 2, 0, 12], [23, 3, 25, 2, 0]):
+        f = Follow(fmt, 48000, 1, [[(0, preset_effect(p, desc.EAX_REVERB if j % 2 == 0 else desc.REVERB))] for j, p in enumerate(presets)])
+        try:
+            b, n = f.b, len(presets)
+            f.mix(256)
+            assert b.plan(0) == (0, n, 0, 0)
+            b.kernel_timing(1)
+            f.mix(256); f.mix(512); f.mix(64)
+            assert b.kernel_timing_read(desc.REVERB + 16)[0] == 0, "the general kernel ran behind proven instances"
+            f.mix(100); f.mix(256)                     # a ragged call: the ragged build, still no follow-up
+            assert b.kernel_timing_read(desc.REVERB + 16)[0] == 0
+            b.set_effect(0, preset_effect(8), first=1, count=1)
+            f.apply()
+            assert b.plan(0) == (0, n - 1, 0, 1)
+            f.mix(256); f.mix(256); f.mix(256)
+            assert b.plan(0) == (0, n, 0, 0)
+            f.check_state()
+        finally:
+            f.close()
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_STEREO, desc.FMT_5POINT1])
+def test_a_broken_host_invariant_is_reported_not_hidden(fmt):
+    """The FP builds have no general path to fall back to, and behind proven multichannel instances no general kernel follows.  If
+    the host ever listed an instance that is not steady (here forced with a test switch: fresh instances, still cross-fading), the
+    kernel counts it and the next synchronising call fails loudly."""
     from oalsfxpp_amd import lib
     from oalsfxpp_amd.api import BatchError
     so = lib.load()
     so.oalsfx_debug_set_flags(0x2000000)
     try:
-        with Batch(5, desc.FMT_STEREO, 48000, 1) as b:
+        with Batch(5, fmt, 48000, 1) as b:
             b.set_effect_type(0, desc.EAX_REVERB)
             b.apply_changes()
-            x = np.zeros((5, 256, 2), dtype=np.float32)
+            x = np.zeros((5, 256, b.channels), dtype=np.float32)
             with pytest.raises(BatchError, match="proven steady"):
                 b.mix(x)
     finally:
