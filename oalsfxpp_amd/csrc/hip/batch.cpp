@@ -662,8 +662,9 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     KernelCtx c = ctx;
     c.progress = hand_over ? b->d_progress : nullptr;
     c.list_first = proven ? b->fast_first[slot] : -1;
-    // the proven-steady instances lead the steady region of the list: the general kernel need not look at them
-    const int lead = hand_over && !(debug_flags() & 0x200000) ? std::max(0, std::min(count, b->steady_offset[slot] + b->fast_count[slot] - offset)) : 0;
+    // the proven-steady instances lead the steady region of the list: in a call of whole tiles (what "proven" vouches for) the
+    // general kernel need not look at them
+    const int lead = hand_over && (ctx.frames & 63) == 0 && !(debug_flags() & 0x200000) ? std::max(0, std::min(count, b->steady_offset[slot] + b->fast_count[slot] - offset)) : 0;
     c.no_follow_up = lead;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);

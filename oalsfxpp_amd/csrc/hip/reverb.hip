@@ -134,6 +134,14 @@ __device__ __forceinline__ void scatter(float v[4], float x, float y)
     v[3] = (x * f3) + (y * (-f0 + -f1 + -f2));
 }
 
+// An output gain that no call of whole tiles will ramp.  The reference ramps a gain over the first frames of a block when
+// |target - current| / frames exceeds FLT_EPSILON and leaves it alone otherwise (for good, if the target is that close: src/oalsfxpp.cpp
+// :2752-2798); the blocks of a whole-tile call are 64 to 256 frames long, and a 64-frame block ramps whatever any longer one would.
+__device__ __forceinline__ bool gain_at_rest(float current, float target)
+{
+    return !(fabsf((target - current) * (1.0F / 64.0F)) > FLT_EPSILON);
+}
+
 // Serial half of a biquad over samples [0, n) of one LDS row: y = (u - a1*y1) - a2*y2.
 // row_u[4+i] holds the feed-forward sums, row_y[4+i] receives the outputs.
 __device__ __forceinline__ void biquad_chain(const float* row_u, float* row_y, int n, float a1, float a2, float& y1, float& y2)
@@ -430,9 +438,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #pragma unroll
             for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
-        // Exactly settled?  Every output gain on its target (not merely within a step that is too small to ramp: that test
-        // depends on the size of the call) -- what the host needs to know before it may list the instance for an FP build.
-        if (!FP && ctx.exact && valid && go && lane == 0) ctx.exact[sidx] = (__ballot(q_valid && !(g_cur == v_gtgt)) == 0ULL) ? 1u : 0u;
+        // At rest?  No output gain that a call of whole tiles would ramp, whatever its size (the test above depends on the size of
+        // this call) -- what the host needs to know before it may list the instance for an FP build.  (The vote is taken by the
+        // whole wavefront, outside the lane-0 branch.)
+        if (!FP && ctx.exact) {
+            const bool at_rest = __ballot(q_valid && !gain_at_rest(g_cur, v_gtgt)) == 0ULL;
+            if (valid && go && lane == 0) ctx.exact[sidx] = at_rest ? 1u : 0u;
+        }
     }
     eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
     has_filter = (FP || (flags & kFiltered) != 0) && instance_has_send_filter(ctx, inst);
@@ -1647,10 +1659,10 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         SS.seen_seq = SP.update_seq;
     }
     if (first && !filtered && lane < channels) send_history_follow(ctx, inst, lane, channels, frames, src);
-    // exactly settled (cross-fade over, every output gain on its target)?  The host reads this back before it lists the instance
-    // for a proven-steady build
+    // settled and at rest (cross-fade over, no output gain that a call of whole tiles would ramp)?  The host reads this back before
+    // it lists the instance for a proven-steady build
     if (ctx.exact) {
-        const bool settled = fade_count >= OALSFX_RV_FADE_SAMPLES && __ballot(q_valid && !(g_cur == g_tgt)) == 0ULL;
+        const bool settled = fade_count >= OALSFX_RV_FADE_SAMPLES && __ballot(q_valid && !gain_at_rest(g_cur, g_tgt)) == 0ULL;
         if (lane == 0) ctx.exact[sidx] = settled ? 1u : 0u;
     }
 }

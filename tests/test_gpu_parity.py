@@ -270,7 +270,8 @@ def test_fused_slot_run_with_send_filters_and_nulls():
     run_batch(desc.FMT_QUAD, 44100, 3, [x[:3] for x in (a, bb, c)], script[:10])
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OALSFX_FUZZ_SEEDS", "32"))))
+# (317: a 5.1 batch in which a proven instance still had an output gain a millionth off its target when a one-frame call came)
+@pytest.mark.parametrize("seed", sorted(set(range(int(__import__("os").environ.get("OALSFX_FUZZ_SEEDS", "32")))) | {317}))
 def test_random_scripts(seed):
     """Random call sequences against the oracle: random effect types and properties per slot (nulls included), property and
     type changes, send filters switched on and off, ragged call sizes, several channel formats and rates."""

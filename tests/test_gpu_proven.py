@@ -173,6 +173,26 @@ def test_proven_path_without_waiting_for_the_stream():
             assert not s.compare_state(), f"instance {i}: state differs"
 
 
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO, desc.FMT_5POINT1])
+def test_output_gains_that_never_reach_their_target(fmt):
+    """The reference ramps an output gain only when |target - current| / frames of the block exceeds FLT_EPSILON, and otherwise leaves
+    the current gain where it is for good (src/oalsfxpp.cpp:2752-2798): with reflections or late reverb almost switched off, current
+    gains stay at zero beside targets of a few millionths -- until a shorter call comes along whose step is large enough.  "Proven
+    steady" must mean that no whole-tile call ramps (64-frame blocks decide), and calls that are not whole tiles must not rely on it."""
+    tiny = [1e-6, 4e-6, 8e-6, 1.2e-5, 2e-5, 5e-5, 2e-4, 1e-3]
+    # (batches of their own: one instance that never comes to rest keeps its whole slot on the believing builds)
+    groups = [[[(0, E(desc.EAX_REVERB, reflections_gain=g, late_reverb_gain=(g if k % 2 else 1.0)))] for k, g in enumerate(tiny)],
+              [[(0, E(desc.EAX_REVERB if k % 2 else desc.REVERB, reflections_gain=0.3, late_reverb_gain=g))] for k, g in enumerate(tiny)]]
+    for setups in groups:
+        f = Follow(fmt, 48000, 1, setups)
+        try:
+            for frames in (256, 256, 256, 64, 64, 256, 1, 256, 64, 2, 128, 2048 + 17, 64, 256, 100, 64, 64):
+                f.mix(frames)
+                f.check_state()   # the current gains are state: a ramp that was skipped shows here even while the gain is inaudible
+        finally:
+            f.close()
+
+
 @pytest.mark.parametrize("fmt", [desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_7POINT1])
 def test_multichannel_proven_instances_skip_the_general_follow_up(fmt):
     """More than two channels: the steady-state kernel hands what it does not take to the general kernel launched right behind it
@@ -188,8 +208,8 @@ def test_multichannel_proven_instances_skip_the_general_follow_up(fmt):
             b.kernel_timing(1)
             f.mix(256); f.mix(512); f.mix(64)
             assert b.kernel_timing_read(desc.REVERB + 16)[0] == 0, "the general kernel ran behind proven instances"
-            f.mix(100); f.mix(256)                     # a ragged call: the ragged build, still no follow-up
-            assert b.kernel_timing_read(desc.REVERB + 16)[0] == 0
+            f.mix(100); f.mix(256)                     # a ragged call: the ragged build, followed up as a whole
+            assert b.kernel_timing_read(desc.REVERB + 16)[0] == 1
             b.set_effect(0, preset_effect(8), first=1, count=1)
             f.apply()
             assert b.plan(0) == (0, n - 1, 0, 1)
