@@ -70,8 +70,8 @@ struct oalsfx_batch {
                                                   // smoother keeps moving long after the depth is set to 0)
     int n_filtered = 0;                           // instances with a send filter switched on
     // What the host *knows* about the reverb slots (as opposed to believes): a slot is proven steady once the device has reported it
-    // exactly settled (d_exact, read back without ever waiting for the stream) and nothing has been uploaded for its instance since.
-    std::vector<uint8_t> proven;                  // [n*slots]
+    // settled and at rest (d_exact, read back without ever waiting for the stream) and nothing has been uploaded for its instance since.
+    std::vector<uint8_t> proven;                  // [n*slots] 0, or from how many tiles a block on the slot's output gains are at rest (1 .. 4)
     std::vector<uint32_t> updated_gen;            // [n*slots] upload generation of the last parameter upload that touched the slot's instance
     std::vector<uint32_t> inst_epoch;             // [n] stamps the hot records: bumped with every upload that touches the instance
     uint32_t upload_gen = 0;
@@ -98,7 +98,7 @@ struct oalsfx_batch {
     int* d_progress = nullptr;                    // [n*slots] hand-off from the steady-state reverb kernel to the general kernel behind it
     unsigned* d_hot = nullptr;                    // [n*slots][hot::SIZE] start records of the proven-steady reverb kernel
     unsigned* d_inst_epoch = nullptr;             // [n]
-    unsigned* d_exact = nullptr;                  // [n*slots] "exactly settled" as the reverb kernels left it
+    unsigned* d_exact = nullptr;                  // [n*slots] "settled and at rest" as the reverb kernels left it
     unsigned* h_exact = nullptr;                  // pinned copy of d_exact, filled by the read-back
     unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
     unsigned* d_fault = nullptr;                  // device address of h_fault
@@ -111,6 +111,7 @@ struct oalsfx_batch {
     int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     int steady_offset[OALSFX_MAX_SLOTS] = {};     // start of the steady region: the proven instances, then the believed ones
     int fast_count[OALSFX_MAX_SLOTS] = {};        // proven steady (both reverb types)
+    int rest_tiles[OALSFX_MAX_SLOTS] = {};        // ... whose output gains are at rest for blocks of that many tiles and longer (1 .. 4)
     int fast_first[OALSFX_MAX_SLOTS] = {};        // >= 0: the proven part of the list is the instance range fast_first, fast_first + 1, ...
     int slow_count[OALSFX_MAX_SLOTS] = {};        // believed steady (both reverb types)
     int general_offset[OALSFX_MAX_SLOTS] = {};
@@ -539,6 +540,13 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
                 b->list_offset[s][OALSFX_REVERB + t] = start[kFast]; // the reverb region as a whole (its types interleave by class)
                 b->list_count[s][OALSFX_REVERB + t] = count[kFast + t] + count[kSlow + t] + count[kGeneral + t];
             }
+            // the shortest block (in tiles) that leaves the gains of every proven instance of the slot alone: calls whose last block
+            // is shorter go through the believing builds
+            b->rest_tiles[s] = 0;
+            for (int i = 0; i < b->n; ++i) {
+                const size_t idx = static_cast<size_t>(i) * b->slots + s;
+                if (b->h_params[idx].type >= OALSFX_REVERB && b->proven[idx] && reverb_settled(b, idx)) b->rest_tiles[s] = std::max<int>(b->rest_tiles[s], b->proven[idx]);
+            }
             b->steady_offset[s] = start[kFast];
             b->fast_count[s] = count[kFast] + count[kFast + 1];
             b->slow_count[s] = count[kSlow] + count[kSlow + 1];
@@ -664,7 +672,10 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     c.list_first = proven ? b->fast_first[slot] : -1;
     // the proven-steady instances lead the steady region of the list: in a call of whole tiles (what "proven" vouches for) the
     // general kernel need not look at them
-    const int lead = hand_over && (ctx.frames & 63) == 0 && !(debug_flags() & 0x200000) ? std::max(0, std::min(count, b->steady_offset[slot] + b->fast_count[slot] - offset)) : 0;
+    // (whose last, shortest block is long enough for the gains of all of them to be at rest)
+    const int n = ctx.frames;
+    const bool vouched = (n & 63) == 0 && (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 >= b->rest_tiles[slot];
+    const int lead = hand_over && vouched && !(debug_flags() & 0x200000) ? std::max(0, std::min(count, b->steady_offset[slot] + b->fast_count[slot] - offset)) : 0;
     c.no_follow_up = lead;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
@@ -768,7 +779,7 @@ int reverb_free_run(const oalsfx_batch* b, int slot)
     return n;
 }
 
-// A finished read-back of the "exactly settled" flags turns believed-steady reverbs into proven ones.  Never waits: an event that
+// A finished read-back of the "settled and at rest" flags turns believed-steady reverbs into proven ones.  Never waits: an event that
 // has not completed yet is looked at again by the next call.
 void poll_exact(oalsfx_batch* b)
 {
@@ -778,7 +789,7 @@ void poll_exact(oalsfx_batch* b)
     for (size_t idx = 0; idx < total; ++idx) {
         // the flag describes the slot as of the read-back's call: usable when nothing was uploaded for the instance after that
         if (b->proven[idx] || !b->h_exact[idx] || b->updated_gen[idx] > b->exact_gen || !reverb_settled(b, idx)) continue;
-        b->proven[idx] = 1;
+        b->proven[idx] = static_cast<uint8_t>(std::min(4u, (b->h_exact[idx] + 63u) / 64u)); // the rest level in tiles: 1 .. 4
         b->lists_dirty = true;
     }
 }
@@ -872,7 +883,10 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             // the proven-steady builds: mono / stereo, whole tiles, a launch of their own
             // ... and only when every steady instance of the slot is proven: a second steady launch beside it costs a fork and a join
             // on this stack (about 27 us), far more than the believing builds cost the proven instances
-            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && b->slow_count[s] == 0 && !(debug_flags() & 0x200000);
+            // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
+            const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
+            const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
+            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && gains_rest && b->slow_count[s] == 0 && !(debug_flags() & 0x200000);
             const int fast = use_fast ? b->fast_count[s] : 0;
             // parts: ring-light effects | proven-steady reverbs | believed-steady reverbs (all steady ones where the proven builds
             // are not in play) | general reverbs

@@ -134,12 +134,20 @@ __device__ __forceinline__ void scatter(float v[4], float x, float y)
     v[3] = (x * f3) + (y * (-f0 + -f1 + -f2));
 }
 
-// An output gain that no call of whole tiles will ramp.  The reference ramps a gain over the first frames of a block when
-// |target - current| / frames exceeds FLT_EPSILON and leaves it alone otherwise (for good, if the target is that close: src/oalsfxpp.cpp
-// :2752-2798); the blocks of a whole-tile call are 64 to 256 frames long, and a 64-frame block ramps whatever any longer one would.
-__device__ __forceinline__ bool gain_at_rest(float current, float target)
+// Output gains at rest.  The reference ramps a gain over the first frames of a block when |target - current| / frames of the block
+// exceeds FLT_EPSILON and leaves it alone otherwise (for good, if the target is that close: src/oalsfxpp.cpp:2752-2798), so a current
+// gain may sit a few millionths off its target forever -- until a call with a shorter block comes along.  The blocks of a call of
+// whole tiles are 64, 128, 192 or 256 frames long.  Returns the shortest of those lengths whose blocks (and all longer ones) leave
+// every gain of the instance alone, 0 if even a 256-frame block would ramp one (a vote of the whole wavefront: `counts` says which
+// lanes hold a gain).  Same expression as the kernels' own "is a ramp in flight" tests.
+__device__ __forceinline__ unsigned gains_rest_level(bool counts, float current, float target)
 {
-    return !(fabsf((target - current) * (1.0F / 64.0F)) > FLT_EPSILON);
+    const float d = target - current;
+    if (__ballot(counts && fabsf(d * (1.0F / 64.0F)) > FLT_EPSILON) == 0ULL) return 64u;
+    if (__ballot(counts && fabsf(d * (1.0F / 128.0F)) > FLT_EPSILON) == 0ULL) return 128u;
+    if (__ballot(counts && fabsf(d * (1.0F / 192.0F)) > FLT_EPSILON) == 0ULL) return 192u;
+    if (__ballot(counts && fabsf(d * (1.0F / 256.0F)) > FLT_EPSILON) == 0ULL) return 256u;
+    return 0u;
 }
 
 // Serial half of a biquad over samples [0, n) of one LDS row: y = (u - a1*y1) - a2*y2.
@@ -265,7 +273,7 @@ struct SteadyShared {
 
 // The work of workgroup `group` of the cooperative kernel (its own kernel below; also one half of k_slot_mixed).
 // FP (with any of plain / HY / MD / ST, whole tiles, mono / stereo): the launch holds only instances the host has *proven* steady
-// (the device reported them exactly settled, DESIGN 4, and nothing has been uploaded for them since).  There is no steady-state
+// (the device reported them settled and at rest, DESIGN 4, and nothing has been uploaded for them since).  There is no steady-state
 // test to fail and no general path to fall back to -- neither its registers, its scratch frame nor its 16 KiB of gain-ramp rows --
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
@@ -438,12 +446,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #pragma unroll
             for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
-        // At rest?  No output gain that a call of whole tiles would ramp, whatever its size (the test above depends on the size of
-        // this call) -- what the host needs to know before it may list the instance for an FP build.  (The vote is taken by the
-        // whole wavefront, outside the lane-0 branch.)
+        // At rest?  From which block length on no output gain would be ramped (the test above depends on the size of this call) --
+        // what the host needs to know before it may list the instance for an FP build.  (The vote is taken by the whole wavefront,
+        // outside the lane-0 branch.)
         if (!FP && ctx.exact) {
-            const bool at_rest = __ballot(q_valid && !gain_at_rest(g_cur, v_gtgt)) == 0ULL;
-            if (valid && go && lane == 0) ctx.exact[sidx] = at_rest ? 1u : 0u;
+            const unsigned level = gains_rest_level(q_valid, g_cur, v_gtgt);
+            if (valid && go && lane == 0) ctx.exact[sidx] = level;
         }
     }
     eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
@@ -1659,11 +1667,11 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
         SS.seen_seq = SP.update_seq;
     }
     if (first && !filtered && lane < channels) send_history_follow(ctx, inst, lane, channels, frames, src);
-    // settled and at rest (cross-fade over, no output gain that a call of whole tiles would ramp)?  The host reads this back before
-    // it lists the instance for a proven-steady build
+    // settled and at rest (cross-fade over; from which block length on no output gain would be ramped)?  The host reads this back
+    // before it lists the instance for a proven-steady build
     if (ctx.exact) {
-        const bool settled = fade_count >= OALSFX_RV_FADE_SAMPLES && __ballot(q_valid && !gain_at_rest(g_cur, g_tgt)) == 0ULL;
-        if (lane == 0) ctx.exact[sidx] = settled ? 1u : 0u;
+        const unsigned level = gains_rest_level(q_valid, g_cur, g_tgt);
+        if (lane == 0) ctx.exact[sidx] = fade_count >= OALSFX_RV_FADE_SAMPLES ? level : 0u;
     }
 }
 

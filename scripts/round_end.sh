@@ -31,3 +31,10 @@ OALSFX_TRAFFIC_REFRESH=1 OALSFX_DEBUG_TIMELINE=/tmp/tl.bin python3 bench.py --st
 K=$(python3 -c "import json; print([json.loads(l) for l in open('$O/bench_timeline_build.json') if l.startswith('{')][-1]['roofline']['kernel_us'])")
 python3 scripts/timeline.py /tmp/tl.bin $K > $O/timeline_steady_kernel.txt || true
 echo "round 2 additions done" >> $O/progress.txt
+# later in round 2: micro-benchmarks behind DESIGN 3.2, and the ring-light types against round 1's library
+hipcc -O3 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 scripts/micro/chain_step.hip -o /tmp/chain_step 2>/dev/null && timeout -k 10 120 /tmp/chain_step > $O/chain_step.txt 2>&1 || true
+hipcc -O3 --offload-arch=gfx950 scripts/micro/placement.hip -o /tmp/placement 2>/dev/null && timeout -k 10 60 /tmp/placement 1024 22272 > $O/workgroup_placement.txt 2>&1 || true
+if [ -f ab/liboalsfx_hip_r01.so ]; then
+  bash scripts/ab_type_libs.sh ab/liboalsfx_hip_r01.so oalsfxpp_amd/csrc/liboalsfx_hip.so 2>/dev/null | grep -E "==|median|b / a" > $O/ab_round1_vs_round2_ring_light_types.txt || true
+fi
+echo "micro-benchmarks done" >> $O/progress.txt
