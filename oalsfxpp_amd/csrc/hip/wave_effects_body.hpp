@@ -668,7 +668,7 @@ struct EchoW {
 };
 
 // distortion (reference src/oalsfxpp.cpp:4675-4750): 4x zero-stuffed oversampling, low-pass, three-stage wave shaper,
-// band-pass, keep every fourth sample.  Three arrays of 4 + 256 floats: low-pass sums/outputs, shaped samples,
+// band-pass, keep every fourth sample.  Arrays of 4 + 256 floats: low-pass sums/outputs, (the shaped samples' two history slots),
 // band-pass sums/outputs; oversampled sample n of the tile belongs to frame n / 4.
 struct DistortionW {
     static constexpr int kArr = 4 + 4 * 64;
@@ -731,28 +731,30 @@ struct DistortionW {
         }
         wave_sync();
         if (lane == 0) advance_row(bp, np); // the band-pass outputs become history before the row takes this tile's sums
-        wave_sync();
         if (L > 0) {
+            // wave shaper and band-pass feed-forward sums, four consecutive oversampled samples per lane, in registers: the two
+            // shaped samples before a lane's four come from the lane below (from the row's history slots for lane 0)
+            const float h2 = sh[2], h1 = sh[3];
+            const float4 y = *reinterpret_cast<const float4*>(lp + 4 + 4 * lane);
             const float fc = p.edge_coeff;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int k = m * 64 + lane;
-                float smp = lp[4 + k];
+            auto shape = [fc](float smp) {
                 smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
                 smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp))) * -1.0F;
                 smp = (1.0F + fc) * smp / (1.0F + (fc * fabsf(smp)));
-                sh[4 + k] = smp;
-            }
-            wave_sync();
+                return smp;
+            };
+            const float x0 = shape(y.x), x1 = shape(y.y), x2 = shape(y.z), x3 = shape(y.w);
+            float p1 = __shfl_up(x3, 1), p2 = __shfl_up(x2, 1);
+            if (lane == 0) { p1 = h1; p2 = h2; }
             const Coef c = coef(p.band_pass);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int k = m * 64 + lane;
-                const float* x = sh + 4 + k;
-                bp[4 + k] = ((c.b0 * x[0]) + (c.b1 * x[-1])) + (c.b2 * x[-2]);
-            }
-            wave_sync();
-            if (lane < 2) advance_row(I.lds + lane * kArr, n);
+            float4 u;
+            u.x = ((c.b0 * x0) + (c.b1 * p1)) + (c.b2 * p2);
+            u.y = ((c.b0 * x1) + (c.b1 * x0)) + (c.b2 * p1);
+            u.z = ((c.b0 * x2) + (c.b1 * x1)) + (c.b2 * x0);
+            u.w = ((c.b0 * x3) + (c.b1 * x2)) + (c.b2 * x1);
+            *reinterpret_cast<float4*>(bp + 4 + 4 * lane) = u;
+            if (lane == L - 1) { sh[2] = x2; sh[3] = x3; } // the shaped samples' history for the next tile
+            if (lane == 0) advance_row(lp, n);
             x_hist0 = 0.0F; x_hist1 = 0.0F;
             wave_sync();
         }
