@@ -821,11 +821,12 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     I.group_lds = group.lds;
     I.group_stride = group.stride;
 
-    // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock around the parts of slot 0's tiles
+    // measurement only (OALSFX_DEBUG_TIMELINE): every 64th instance stamps the shader clock around the parts of its tiles, 24 stamps per
+    // slot (scripts/timeline_wave.py, timeline_slots.py)
     int ts_i = 0;
     auto stamp = [&]() {
-        if (ctx.timeline && slot == 0 && (inst & 63) == 0 && (inst >> 6) < 64 && lane == 0 && ts_i < 96)
-            ctx.timeline[64 * 4 * 96 + (inst >> 6) * 96 + ts_i++] = clock64();
+        if (ctx.timeline && (inst & 63) == 0 && (inst >> 6) < 64 && lane == 0 && ts_i < 24)
+            ctx.timeline[64 * 4 * 96 + (inst >> 6) * 96 + (slot & 3) * 24 + ts_i++] = clock64();
     };
     stamp();
     Fx fx;

@@ -13,7 +13,7 @@ b.set_effect_type(0, t); b.apply_changes()
 src = torch.empty(n * frames * 2, device="cuda").uniform_(-1, 1); dst = torch.empty_like(src)
 for _ in range(8): b.mix_device(frames, src.data_ptr(), dst.data_ptr())
 b.synchronize(); b.close()
-raw = np.fromfile("gpurun_out/timeline_wave.bin", dtype=np.uint64)[64 * 4 * 96:].reshape(64, 96)
+raw = np.fromfile("gpurun_out/timeline_wave.bin", dtype=np.uint64)[64 * 4 * 96:].reshape(64, 96)[:, :24]  # slot 0's stamps
 rows = []
 for w in raw:
     k = int(np.count_nonzero(w))
