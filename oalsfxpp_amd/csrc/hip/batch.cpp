@@ -621,7 +621,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
 // through the believing builds), 0x400000 ring-light workgroups longest type first instead of in list (type) order, 0x800000 oalsfx_batch_mix_async copies page-locked
 // buffers with kernels instead of the runtime's copy engines, 0x2000000 every reverb listed as proven steady whatever the device said
-// (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks
+// (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks, 0x8000000 no
+// fused runs of reverb-free slots (one launch per slot; config 3: 107.6 - 108.1 against 107.5 us per step)
 int g_debug_flags = -1;
 int debug_flags()
 {
@@ -856,7 +857,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         for (int s = 0; s < b->slots; ++s) {
             ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
             const int run = reverb_free_run(b, s);
-            if (run >= 2) {
+            if (run >= 2 && !(debug_flags() & 0x8000000)) {
                 // slots s .. s+run-1 hold ring-light effects (or nothing) for every instance: one launch, one wavefront per
                 // instance, the slots in order inside it; the slot's list in type order lists every instance exactly once
                 const int run_flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s + run == b->slots ? oalsfx_hip::kLast : 0) |
