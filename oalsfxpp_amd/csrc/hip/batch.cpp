@@ -588,16 +588,27 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         if (n_src) std::memcpy(st->host + o_ep, up_epoch.data(), n_src * sizeof(uint32_t));
         if (rings_changed) std::memcpy(st->host + o_rt, b->h_rings.data(), total * sizeof(float*));
         if (rebuild_lists) std::memcpy(st->host + o_li, lists.data(), total * sizeof(int));
-        if (!b->hip_ok(hipMemcpyAsync(st->dev, st->host, off, hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(parameters)")) return false;
+        // Small uploads (parameter changes while streaming) are read by the kernels straight from the page-locked staging buffer: a
+        // copy-engine transfer between two kernels of one stream is ordered through the host on this stack and started ~90 us after
+        // the kernel before it had ended (rocprofv3 trace of scripts/update_storm_bench.py), with the host waiting for it a step later.
+        // Bulk uploads (creation of a batch) keep the transfer.
+        const bool direct = off <= (static_cast<size_t>(1) << 20) && !(debug_flags() & 0x10000000);
+        const char* from = direct ? st->host : st->dev;
+        if (!direct && !b->hip_ok(hipMemcpyAsync(st->dev, st->host, off, hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(parameters)")) return false;
+        // one launch puts everything in place
+        auto words = [&](size_t o) { return reinterpret_cast<const unsigned*>(from + o); };
+        auto ints = [&](size_t o) { return reinterpret_cast<const int*>(from + o); };
+        oalsfx_hip::UploadJobs jobs{};
+        jobs.scatter[0] = {reinterpret_cast<unsigned*>(b->d_params), words(o_pr), ints(o_pi), static_cast<int>(sizeof(oalsfx_slot_params) / 4), static_cast<int>(n_p)};
+        jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_slot_state) / 4), static_cast<int>(n_s)};
+        jobs.scatter[2] = {reinterpret_cast<unsigned*>(b->d_source), words(o_cr), ints(o_ci), static_cast<int>(sizeof(oalsfx_source_params) / 4), static_cast<int>(n_src)};
+        jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ci), 1, static_cast<int>(n_src)};
+        jobs.copy[0] = {reinterpret_cast<unsigned*>(b->d_rings), words(o_rt), rings_changed ? total * (sizeof(float*) / 4) : 0, 0};
+        jobs.copy[1] = {reinterpret_cast<unsigned*>(b->d_lists), words(o_li), rebuild_lists ? total : 0, 0};
+        oalsfx_hip::launch_upload(jobs, b->stream);
+        // the staging buffer is free again once everything that reads it has run
         if (!b->hip_ok(hipEventRecord(st->done, b->stream), "hipEventRecord")) return false;
         st->pending = true;
-        using oalsfx_hip::launch_scatter_records;
-        launch_scatter_records(b->d_params, sizeof(oalsfx_slot_params), st->dev + o_pr, reinterpret_cast<const int*>(st->dev + o_pi), static_cast<int>(n_p), b->stream);
-        launch_scatter_records(b->d_state, sizeof(oalsfx_slot_state), st->dev + o_sr, reinterpret_cast<const int*>(st->dev + o_si), static_cast<int>(n_s), b->stream);
-        launch_scatter_records(b->d_source, sizeof(oalsfx_source_params), st->dev + o_cr, reinterpret_cast<const int*>(st->dev + o_ci), static_cast<int>(n_src), b->stream);
-        launch_scatter_records(b->d_inst_epoch, sizeof(uint32_t), st->dev + o_ep, reinterpret_cast<const int*>(st->dev + o_ci), static_cast<int>(n_src), b->stream);
-        if (rings_changed && !b->hip_ok(hipMemcpyAsync(b->d_rings, st->dev + o_rt, total * sizeof(float*), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(ring table)")) return false;
-        if (rebuild_lists && !b->hip_ok(hipMemcpyAsync(b->d_lists, st->dev + o_li, total * sizeof(int), hipMemcpyDeviceToDevice, b->stream), "hipMemcpyAsync(lists)")) return false;
         if (!b->hip_ok(hipGetLastError(), "parameter upload")) return false;
     }
     // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
@@ -622,11 +633,12 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // through the believing builds), 0x400000 ring-light workgroups longest type first instead of in list (type) order, 0x800000 oalsfx_batch_mix_async copies page-locked
 // buffers with kernels instead of the runtime's copy engines, 0x2000000 every reverb listed as proven steady whatever the device said
 // (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks, 0x8000000 no
-// fused runs of reverb-free slots (one launch per slot; config 3: 107.6 - 108.1 against 107.5 us per step)
+// fused runs of reverb-free slots (one launch per slot; config 3: 118.4 against 107.5 us per step), 0x10000000 small parameter
+// uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step)
 int g_debug_flags = -1;
 int debug_flags()
 {
-    if (g_debug_flags < 0) g_debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? std::atoi(std::getenv("OALSFX_DEBUG_FLAGS")) : 0;
+    if (g_debug_flags < 0) g_debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? static_cast<int>(std::strtol(std::getenv("OALSFX_DEBUG_FLAGS"), nullptr, 0)) : 0; // decimal or 0x...
     return g_debug_flags;
 }
 

@@ -120,6 +120,12 @@ void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_s
                          hipStream_t stream);
 // record k of `packed` (count records of record_bytes, a multiple of 4) goes to slot indices[k] of the device array `dst`
 void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, const int* indices, int count, hipStream_t stream);
+// A whole parameter upload in one launch: record k of `packed` goes to slot indices[k] of `dst` (four arrays), and two plain copies
+// (dword counts; 16-byte aligned).  Sources may be page-locked host memory.
+struct ScatterJob { unsigned* dst; const unsigned* packed; const int* indices; int record_dwords; int count; };
+struct CopyJob { unsigned* dst; const unsigned* src; size_t dwords; int blocks; };
+struct UploadJobs { ScatterJob scatter[4]; CopyJob copy[2]; };
+void launch_upload(UploadJobs jobs, hipStream_t stream);
 void launch_null(hipStream_t stream);
 // dst[0 .. floats) = src[0 .. floats), either of them possibly page-locked host memory mapped into the device's address space
 void launch_copy_floats(float* dst, const float* src, size_t floats, hipStream_t stream);

@@ -1285,14 +1285,20 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                 lap_limit = min_positive(lap_limit, P.late_ap_off[j]);
             }
         }
-        // steady state: which tap groups lie entirely before a full tile and can be fetched up front
-        const bool pre = !faded;
-        const bool pre_e = pre && min4(cur_etap) >= 64;
-        const bool pre_a = pre && min4(cur_eap) >= 64;
-        const bool pre_el = pre && min4(cur_eline) >= 64;
-        const bool pre_lt = pre && min4(cur_ltap) >= P.late_feed_tap + 64;
-        const bool pre_la = pre && min4(cur_lap) >= 64;
-        const bool pre_ll = pre_la && !mod_active && min4(cur_lline) >= 64;
+        // which tap groups lie entirely before a full tile and can be fetched up front (while cross-fading: the taps faded in as well)
+        auto far = [&](const int* cur, const int* target, int least) { return min4(cur) >= least && (!faded || min4(target) >= least); };
+        int n_etap[4], n_eap[4], n_eline[4], n_ltap[4], n_lap[4], n_lline[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            n_etap[j] = P.early_tap[j]; n_eap[j] = P.early_ap_off[j]; n_eline[j] = P.early_line_off[j];
+            n_ltap[j] = P.late_tap[j]; n_lap[j] = P.late_ap_off[j]; n_lline[j] = P.late_line_off[j];
+        }
+        const bool pre_e = far(cur_etap, n_etap, 64);
+        const bool pre_a = far(cur_eap, n_eap, 64);
+        const bool pre_el = far(cur_eline, n_eline, 64);
+        const bool pre_lt = far(cur_ltap, n_ltap, P.late_feed_tap + 64);
+        const bool pre_la = far(cur_lap, n_lap, 64);
+        const bool pre_ll = pre_la && !mod_active && far(cur_lline, n_lline, 64);
         for (int done = 0; done < todo; done += 64) {
             const int L = min(64, todo - done);
             const bool act = lane < L;
@@ -1338,6 +1344,24 @@ __device__ __forceinline__ void reverb_general_instance(const KernelCtx& ctx, in
                     if (pre_lt) p_lt[j] = ld(slab_b, r_main.at(j, t4 - 4u * cur_ltap[j]));
                     if (pre_ll) p_ll[j] = ld(slab_b, r_lline.at(j, t4 - 4u * cur_lline[j]));
                     if (pre_la) p_la[j] = ld(slab_b, r_lap.at(j, t4 - 4u * cur_lap[j]));
+                }
+            }
+            if (faded) {
+                // cross-fading: the taps being faded in travel with them, and the two are mixed here as delay_out_faded does
+                // (reference src/oalsfxpp.cpp:7358-7399), one round trip for the tile instead of one in front of every stage
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float q_e = 0.0F, q_a = 0.0F, q_el = 0.0F, q_lt = 0.0F, q_ll = 0.0F, q_la = 0.0F;
+                    if (act) {
+                        if (pre_e) q_e = ld(slab_b, r_main.at(j, t4 - 4u * n_etap[j]));
+                        if (pre_a) q_a = ld(slab_b, r_eap.at(j, t4 - 4u * n_eap[j]));
+                        if (pre_el) q_el = ld(slab_b, r_eline.at(j, t4 - 4u * n_eline[j]));
+                        if (pre_lt) q_lt = ld(slab_b, r_main.at(j, t4 - 4u * n_ltap[j]));
+                        if (pre_ll) q_ll = ld(slab_b, r_lline.at(j, t4 - 4u * n_lline[j]));
+                        if (pre_la) q_la = ld(slab_b, r_lap.at(j, t4 - 4u * n_lap[j]));
+                    }
+                    p_e[j] = lerpf(p_e[j], q_e, fade); p_a[j] = lerpf(p_a[j], q_a, fade); p_el[j] = lerpf(p_el[j], q_el, fade);
+                    p_lt[j] = lerpf(p_lt[j], q_lt, fade); p_ll[j] = lerpf(p_ll[j], q_ll, fade); p_la[j] = lerpf(p_la[j], q_la, fade);
                 }
             }
             if (!first && act) {

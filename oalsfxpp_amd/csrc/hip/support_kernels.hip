@@ -296,6 +296,47 @@ void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, 
                        static_cast<const unsigned*>(packed), indices, count);
 }
 
+// ---- the same for everything a parameter upload consists of, in one launch: up to four scatters and two plain copies.  The sources
+// may lie in page-locked host memory (small uploads are read from the staging buffer directly): one launch then costs one round of
+// reads over the link instead of one per array.
+__global__ __launch_bounds__(64) void k_upload(UploadJobs jobs)
+{
+    int k = blockIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const ScatterJob& sj = jobs.scatter[j];
+        if (k < sj.count) {
+            const size_t to = static_cast<size_t>(sj.indices[k]) * sj.record_dwords, from = static_cast<size_t>(k) * sj.record_dwords;
+            for (int i = threadIdx.x; i < sj.record_dwords; i += 64) sj.dst[to + i] = sj.packed[from + i];
+            return;
+        }
+        k -= sj.count;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const CopyJob& cj = jobs.copy[j];
+        if (k < cj.blocks) {
+            // 1024 dwords per block, 16 bytes per lane and round
+            const size_t lo = static_cast<size_t>(k) * 1024, hi = lo + 1024 < cj.dwords ? lo + 1024 : cj.dwords;
+            for (size_t i = lo + 4 * threadIdx.x; i < hi; i += 256) {
+                if (i + 4 <= hi) *reinterpret_cast<uint4*>(cj.dst + i) = *reinterpret_cast<const uint4*>(cj.src + i);
+                else for (size_t q = i; q < hi; ++q) cj.dst[q] = cj.src[q];
+            }
+            return;
+        }
+        k -= cj.blocks;
+    }
+}
+
+void launch_upload(UploadJobs jobs, hipStream_t stream)
+{
+    int blocks = 0;
+    for (auto& sj : jobs.scatter) blocks += sj.count > 0 ? sj.count : (sj.count = 0);
+    for (auto& cj : jobs.copy) { cj.blocks = static_cast<int>((cj.dwords + 1023) / 1024); blocks += cj.blocks; }
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(64), 0, stream, jobs);
+}
+
 // ---- buffer copies between page-locked host memory and device memory as a kernel (oalsfx_batch_mix_async): the copy engines of some
 // hosts run the two directions far below the link's rate when both are busy; a grid of wavefronts reading or writing the mapped host
 // buffer does not depend on them.  16 bytes per lane, grid-stride.

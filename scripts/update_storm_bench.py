@@ -21,14 +21,17 @@ for k in levels:
         b.mix_device(frames, src.data_ptr(), dst.data_ptr())
     b.synchronize()
     t_upd = 0.0
+    t_mix = 0.0
     t0 = time.perf_counter()
     for step in range(50):
         u0 = time.perf_counter()
         for i in rng.sample(range(n), k):
             b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
         if k: b.apply_changes()
-        t_upd += time.perf_counter() - u0
+        u1 = time.perf_counter()
+        t_upd += u1 - u0
         b.mix_device(frames, src.data_ptr(), dst.data_ptr())
+        t_mix += time.perf_counter() - u1
     b.synchronize()
     dt = (time.perf_counter() - t0) / 50
-    print(f"{k:5d} updates per buffer: step {dt*1e6:8.1f} us (of which the setter calls from Python {t_upd/50*1e6:8.1f} us)", flush=True)
+    print(f"{k:5d} updates per buffer: step {dt*1e6:8.1f} us (of which the setter calls from Python {t_upd/50*1e6:8.1f} us, the host inside mix_device {t_mix/50*1e6:8.1f} us)", flush=True)
