@@ -779,9 +779,14 @@ void launch_mixed_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     const int steady = b->fast_count[slot] + b->slow_count[slot];
     KernelCtx c = ctx;
     c.progress = nullptr; // an instance that turns out not to be steady falls back inside the grid
+    // all of them proven, and a call whose last block leaves their gains at rest: the reverb groups take the FP build
+    const int n = ctx.frames;
+    const bool proven = b->slow_count[slot] == 0 && b->fast_count[slot] > 0 && (n & 63) == 0 &&
+                        (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 >= b->rest_tiles[slot] && !(debug_flags() & 0x200000);
+    c.list_first = proven ? b->fast_first[slot] : -1;
     ScopedTiming timing(b, kTimedMixed, stream);
     oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->steady_offset[slot], steady, b->d_lists + b->list_offset[slot][first_type], light,
-                                  seg, flags, stream);
+                                  seg, flags, proven, stream);
 }
 
 // Number of consecutive slots from `slot` on that hold no reverb at all: such a run is one fused launch over every instance.

@@ -112,8 +112,9 @@ void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int 
 void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, const WaveSegments* seg, int flags,
                          hipStream_t stream);
 // mono / stereo, whole tiles: the believed-steady reverbs and the ring-light effects of one slot in one grid (reverb.hip)
+// (`proven`: every listed reverb is proven steady and the call's blocks leave their gains at rest: the FP build of the reverb groups)
 void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
-                       const WaveSegments& seg, int flags, hipStream_t stream);
+                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,

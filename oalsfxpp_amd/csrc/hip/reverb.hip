@@ -1724,31 +1724,38 @@ __global__ __launch_bounds__(256, CH == 8 ? 1 : 2) void k_reverb(KernelCtx ctx, 
 // first workgroups are groups of the cooperative reverb kernel (its most general build: the reverbs of such a batch rarely
 // share properties), the others run one ring-light instance per wavefront.  Two launches on two streams do the same work
 // concurrently, but ordering them against the caller's stream costs ~7 us at the fork and ~20 us at the join on this stack.
-template <int CH, bool RG>
+// FP: every reverb of the grid is proven steady (whole-tile calls): the reverb groups run the build without steady-state test and
+// general path, started from hot records.
+template <int CH, bool RG, bool FP = false>
 __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, const int* __restrict__ steady_list, int steady_count,
                                                        const int* __restrict__ light_list, int light_count, WaveSegments seg, int flags)
 {
     union Shared {
-        SteadyShared<CH, 4> steady;
+        SteadyShared<CH, 4, FP, true, true> steady;
         float light[4][wfx::kLdsFloats];
     };
     __shared__ Shared sh;
     const int steady_groups = (steady_count + 3) >> 2;
     const int group = static_cast<int>(blockIdx.x);
     if (group < steady_groups) {
-        reverb_steady_group<CH, 4, false, true, true, true, RG>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
+        reverb_steady_group<CH, 4, false, true, true, true, RG, FP>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
         return;
     }
     wfx::wave_block<CH>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
 }
 
 void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
-                       const WaveSegments& seg, int flags, hipStream_t stream)
+                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream)
 {
     if (ctx.frames <= 0 || steady_count + light_count <= 0) return;
     const int light_blocks = seg.n > 0 ? seg.blocks() : (light_count + 3) / 4;
     const dim3 grid((steady_count + 3) / 4 + light_blocks), block(256);
     const bool ragged = (ctx.frames & 63) != 0;
+    if (proven && !ragged) {
+        if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1, false, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+        else OALSFX_LAUNCH((k_slot_mixed<2, false, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
+        return;
+    }
     if (ctx.channels == 1 && ragged) OALSFX_LAUNCH((k_slot_mixed<1, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
     else if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1, false>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);
     else if (ragged) OALSFX_LAUNCH((k_slot_mixed<2, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);

@@ -147,6 +147,32 @@ def test_proven_reverbs_beside_other_slots_and_filters():
         f.close()
 
 
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_proven_reverbs_in_a_slot_shared_with_ring_light_effects(fmt):
+    """BASELINE configs[3]'s shape: one slot, reverbs for some instances and ring-light effects for the others, served by one grid.
+    Once every reverb of the slot is proven its groups run the build without steady-state test; a ragged call, a change and a
+    64-frame call behind gains that only 256-frame calls leave alone go back to the believing build."""
+    setups = [[(0, preset_effect(0))], [(0, E(desc.CHORUS))], [(0, preset_effect(23, desc.REVERB))], [(0, E(desc.DISTORTION))], [(0, E(desc.ECHO))],
+              [(0, preset_effect(3))], [(0, E(desc.EQUALIZER))], [(0, E(desc.EAX_REVERB, late_reverb_gain=2e-5))], [(0, E(desc.COMPRESSOR))],
+              [(0, preset_effect(2))], [(0, E(desc.RING_MODULATOR))], [(0, E(desc.FLANGER))]]
+    f = Follow(fmt, 48000, 1, setups)
+    try:
+        b = f.b
+        for frames in (256, 256, 256, 256, 512, 256, 100, 256, 256, 64, 64, 256):
+            f.mix(frames)
+            f.check_state()
+        assert b.plan(0) == (7, 5, 0, 0)
+        b.set_effect(0, preset_effect(40), first=5, count=1)
+        f.apply()
+        assert b.plan(0) == (7, 4, 0, 1)
+        for frames in (256, 256, 256, 256):
+            f.mix(frames)
+        assert b.plan(0) == (7, 5, 0, 0)
+        f.check_state()
+    finally:
+        f.close()
+
+
 def test_proven_path_without_waiting_for_the_stream():
     """Device-resident buffers, no synchronising call between the mixes: the read-back of the settled flags arrives whenever it
     arrives, the host promotes then; results are the same whichever kernel took an instance."""
