@@ -141,7 +141,8 @@ struct oalsfx_batch {
     // Parameter uploads: the changed records are packed into pinned memory, copied in one piece and scattered on the device;
     // two buffers take turns so that the host never waits for the stream.
     struct Stage { char* host = nullptr; char* dev = nullptr; size_t capacity = 0; hipEvent_t done = nullptr; bool pending = false; };
-    Stage stage[2];
+    Stage stage[4];                               // (four: an event of this stack is seen complete only once the launch behind it has run,
+                                                  // so the buffer of two uploads ago would still make the host wait for the GPU)
     int stage_turn = 0;
     hipEvent_t ev_uploaded = nullptr;             // parameter uploads of the batch's own stream -> a caller's launch stream
     hipEvent_t ev_mixed = nullptr;                // last launch on a caller's stream -> parameter uploads that overwrite what it reads
@@ -369,13 +370,21 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
 // read it has completed, which by then is two rounds old).
 oalsfx_batch::Stage* acquire_stage(oalsfx_batch* b, size_t bytes)
 {
-    oalsfx_batch::Stage& st = b->stage[b->stage_turn];
-    b->stage_turn ^= 1;
-    if (!st.done && !b->hip_ok(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "hipEventCreate")) return nullptr;
-    if (st.pending) {
-        if (!b->hip_ok(hipEventSynchronize(st.done), "hipEventSynchronize")) return nullptr;
-        st.pending = false;
+    // the first buffer, oldest first, whose launch has run (a query: waiting for an event, however old, makes the host wait for
+    // everything that is queued on this stack); only if all four are still being read does the host wait for the oldest
+    int pick = -1;
+    for (int k = 0; k < 4 && pick < 0; ++k) {
+        oalsfx_batch::Stage& c = b->stage[(b->stage_turn + k) & 3];
+        if (!c.pending || hipEventQuery(c.done) == hipSuccess) pick = (b->stage_turn + k) & 3;
     }
+    if (pick < 0) {
+        pick = b->stage_turn;
+        if (!b->hip_ok(hipEventSynchronize(b->stage[pick].done), "hipEventSynchronize")) return nullptr;
+    }
+    oalsfx_batch::Stage& st = b->stage[pick];
+    b->stage_turn = (pick + 1) & 3;
+    st.pending = false;
+    if (!st.done && !b->hip_ok(hipEventCreateWithFlags(&st.done, hipEventDisableTiming), "hipEventCreate")) return nullptr;
     if (bytes > st.capacity) {
         if (st.host) (void)hipHostFree(st.host);
         if (st.dev) (void)hipFree(st.dev);
@@ -634,7 +643,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // buffers with kernels instead of the runtime's copy engines, 0x2000000 every reverb listed as proven steady whatever the device said
 // (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks, 0x8000000 no
 // fused runs of reverb-free slots (one launch per slot; config 3: 118.4 against 107.5 us per step), 0x10000000 small parameter
-// uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step)
+// uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step), 0x20000000 the
+// caller's stream takes a slot's first part instead of its general kernel
 int g_debug_flags = -1;
 int debug_flags()
 {
@@ -913,12 +923,18 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             for (bool on : part_on) parts += on;
             const bool fork = parts > 1 && !(debug_flags() & 0x20000);
             if (fork && !b->hip_ok(hipEventRecord(b->ev_fork, stream), "hipEventRecord")) return false;
+            // The caller's stream takes the part the step will wait for longest -- the general kernel, if there is one (a few
+            // wavefronts, each a long chain of latencies) -- and the others go beside it: what the stream then waits for at the
+            // join has long finished, and neither fork nor join (about 12 us each on this stack) lies on the step's critical path.
+            int main_part = -1;
+            for (int g = 0; g < 4; ++g)
+                if (part_on[g]) main_part = (main_part < 0 || g == 3) ? g : main_part;
+            if (debug_flags() & 0x20000000) { main_part = -1; for (int g = 3; g >= 0; --g) if (part_on[g]) main_part = g; } // experiment: the first part, as before
             int side = 0;
-            bool main_taken = false;
             for (int g = 0; g < 4; ++g) {
                 if (!part_on[g]) continue;
                 hipStream_t gs = stream;
-                if (fork && main_taken) {
+                if (fork && g != main_part) {
                     gs = b->side_stream[side];
                     if (!b->hip_ok(hipStreamWaitEvent(gs, b->ev_fork, 0), "hipStreamWaitEvent")) return false;
                 }
@@ -935,11 +951,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 }
                 if (gs != stream) {
                     if (!b->hip_ok(hipEventRecord(b->ev_join[side], gs), "hipEventRecord")) return false;
-                    if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_join[side], 0), "hipStreamWaitEvent")) return false;
                     ++side;
                 }
-                main_taken = true;
             }
+            for (int k = 0; k < side; ++k)
+                if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_join[k], 0), "hipStreamWaitEvent")) return false;
         }
         done += n;
     }
