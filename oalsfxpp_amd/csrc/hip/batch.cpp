@@ -909,8 +909,9 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
             const bool mixed = light > 0 && steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
             // the proven-steady builds: mono / stereo, whole tiles, a launch of their own
-            // ... and only when every steady instance of the slot is proven: a second steady launch beside it costs a fork and a join
-            // on this stack (about 27 us), far more than the believing builds cost the proven instances
+            // ... and only when every steady instance of the slot is proven: a second steady launch beside it costs more than the
+            // believing builds cost the proven instances (4 send changes per buffer among 4096 reverbs: 92.8 against 68.2 us per step,
+            // scripts/send_change_bench.py; re-measured with the side launches off the critical path)
             // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
             const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
             const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
