@@ -233,6 +233,37 @@ def roofline_region(batch, src, dst, n_in, first_step, bytes_per_launch):
     }
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: this process (which has neither imported torch nor touched HIP) starts N fresh
+    rank processes of the same command line, one per GPU, with the rendezvous variables torch.distributed.run would set; rank 0's
+    output is relayed.  Returns the exit status: non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    status = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                for q in pending:  # a rank that failed would leave the others waiting at the rendezvous
+                    q.terminate()
+        time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,7 +282,12 @@ def main():
                                                            "the `config5` object; always on when --gpus > 1")
     ap.add_argument("--host-io", type=int, default=10, metavar="K",
                     help="after the timed region, also time K steps through the host-pointer entry points (PCIe both ways)")
+    ap.add_argument("--no-config5", action="store_true", help="multi-GPU runs: leave the `config5` object out (rehearsals on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before torch or HIP are touched in this process)
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -260,16 +296,22 @@ def main():
     from oalsfxpp_amd.api import Batch
 
     rank, world, local_rank = sharding.env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would misstate n_gpus")
     distributed = world > 1
+    # RCCL ("nccl") between the ranks; OALSFX_DIST_BACKEND=gloo is for rehearsing the N > 1 path where the ranks share a GPU
+    backend = os.environ.get("OALSFX_DIST_BACKEND", "nccl")
     # one process per GPU: LOCAL_RANK picks the device; if the launcher narrowed the visible devices to one per process
     # (HIP_VISIBLE_DEVICES), that one is device 0
     visible = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if distributed and backend == "nccl" and visible < local_world and visible != 1:
+        raise SystemExit(f"--gpus {args.gpus}: {local_world} ranks on this node but only {visible} GPUs visible (one process per GPU)")
+    if distributed and backend == "nccl" and visible == 1 and not (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")):
+        raise SystemExit(f"--gpus {args.gpus}: one GPU visible and no per-rank visibility mask: {local_world} ranks would share it "
+                         "(OALSFX_DIST_BACKEND=gloo rehearses that on purpose)")
     local_rank = local_rank % visible if visible > 0 else local_rank
     torch.cuda.set_device(local_rank)
-    # RCCL ("nccl") between the ranks; OALSFX_DIST_BACKEND=gloo is for rehearsing the N > 1 path where the ranks share a GPU
-    backend = os.environ.get("OALSFX_DIST_BACKEND", "nccl")
     if distributed:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -376,11 +418,14 @@ def main():
         if os.environ.get("OALSFX_TRAFFIC_REFRESH"):
             t = {}  # the counter passes that produce the next traffic.json run this very script (scripts/profile_pmc.sh)
         elif t.get("kernel") != roofline["kernel"]:
-            # the committed counter run belongs to another kernel: say so instead of attaching its bytes to this one
-            raise SystemExit(f"profiles/traffic.json was measured on {t.get('kernel')!r} but this run launched {roofline['kernel']!r}: "
-                             "refresh it from a --pmc pass of this build (scripts/profile_pmc.sh)")
+            # the committed counter run belongs to another kernel (an experiment flag, a preset that selects another build, a run whose
+            # instances were not all proven yet): its bytes are not attached to this one
+            result["roofline"]["traffic_note"] = (f"profiles/traffic.json was measured on {t.get('kernel')!r}, this run launched "
+                                                  f"{roofline['kernel']!r}: no counter traffic for it (scripts/profile_pmc.sh refreshes the file)")
+            t = {}
         result["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-        result["roofline"]["traffic_source"] = t.get("source")
+        if t:
+            result["roofline"]["traffic_source"] = t.get("source")
 
     if os.environ.get("OALSFX_DUMP_OUTPUT"):
         # rehearsal hook (tests/test_gpu_async_and_ranks.py): this rank's last output buffer, to compare with a single-process run
@@ -392,7 +437,7 @@ def main():
     del src, dst
     torch.cuda.empty_cache()
 
-    if (args.config5 or distributed) and not config5_main:
+    if (args.config5 or distributed) and not config5_main and not args.no_config5:
         result["config5"] = config5_leg(rank, world, local_rank, min(args.steps, 100), sharding, backend)
 
     if distributed:
@@ -417,12 +462,30 @@ def host_io_leg(batch, n, steps):
     call = lambda k: so.oalsfx_batch_mix(batch._h, FRAMES, C.cast(hsrc[k % depth].data_ptr(), fp), C.cast(hdst[k % depth].data_ptr(), fp))
     for k in range(3):
         assert call(k)
+    per_step = []
     t0 = time.perf_counter()
     for k in range(steps):
+        t1 = time.perf_counter()
         assert call(k)
+        per_step.append((time.perf_counter() - t1) * 1e3)
     dt = time.perf_counter() - t0
+    per_step.sort()
     out = {"value": round(n * FRAMES * steps / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+           "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(percentile(per_step, 0.5), 4), "ms_per_step_max": round(per_step[-1], 4),
            "note": "pinned host src/dst, H2D + kernels + D2H + sync per step, not overlapped"}
+    if hasattr(so, "oalsfx_batch_mix_timed"):
+        # where a step's time goes: the three legs as HIP events on the batch's stream see them, and the host's own clock around the call
+        legs = (C.c_double * 3)()
+        rows = []
+        for k in range(steps):
+            t1 = time.perf_counter()
+            assert so.oalsfx_batch_mix_timed(batch._h, FRAMES, C.cast(hsrc[k % depth].data_ptr(), fp), C.cast(hdst[k % depth].data_ptr(), fp), legs)
+            rows.append((legs[0], legs[1], legs[2], (time.perf_counter() - t1) * 1e6))
+        med = lambda j: round(percentile(sorted(r[j] for r in rows), 0.5), 1)
+        out["legs_us_median"] = {"h2d": med(0), "kernels": med(1), "d2h": med(2), "host_wall": med(3),
+                                 "note": "oalsfx_batch_mix_timed; host_wall - (h2d + kernels + d2h) = queueing and the wake-up after hipStreamSynchronize"}
+        out["legs_us_max"] = {"h2d": round(max(r[0] for r in rows), 1), "kernels": round(max(r[1] for r in rows), 1),
+                              "d2h": round(max(r[2] for r in rows), 1), "host_wall": round(max(r[3] for r in rows), 1)}
     if hasattr(so, "oalsfx_batch_mix_async"):
         acall = lambda k: so.oalsfx_batch_mix_async(batch._h, FRAMES, C.cast(hsrc[k % depth].data_ptr(), fp), C.cast(hdst[k % depth].data_ptr(), fp))
         psteps = max(steps, 30)

@@ -72,6 +72,9 @@ int oalsfx_batch_apply_changes(oalsfx_batch* b, int first, int count);
  * src and dst hold n_instances * frames * channels floats.  frames may be any positive count;
  * more than 2048 are processed in 2048-frame chunks like the reference.  frames == 0 succeeds. */
 int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host);
+/* The same call with its three legs timed by HIP events on the batch's stream: legs_us[0] the copy in, [1] the kernels, [2] the copy
+ * out, in microseconds (a measurement aid: bench.py's host_io object says with it where a slow box loses the time). */
+int oalsfx_batch_mix_timed(oalsfx_batch* b, int frames, const float* src_host, float* dst_host, double legs_us[3]);
 /* Same with buffers already resident in device memory; launches on `hip_stream` (a hipStream_t, or
  * NULL for the batch's own stream) and returns without synchronising. */
 int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream);

@@ -5,6 +5,7 @@ method names of the reference's `oalsfxpp::Api` (reference src/oalsfxpp.h:760-92
 every call goes straight to liboalsfx_hip.so, nothing is computed in Python.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -35,9 +36,6 @@ class Batch:
         if getattr(self, "_h", None):
             self._lib.oalsfx_batch_destroy(self._h)
             self._h = None
-            for p in getattr(self, "_pinned", []):
-                self._lib.oalsfx_pinned_free(C.c_void_p(p))
-            self._pinned = []
 
     def __del__(self):
         self.close()
@@ -116,15 +114,17 @@ class Batch:
         self._check(self._lib.oalsfx_batch_wait(self._h))
 
     def pinned_array(self, frames):
-        """A page-locked float32 array [n][frames][channels] (freed with the returned array's base buffer: keep the Batch's library loaded)."""
+        """A page-locked float32 array [n][frames][channels].  The allocation belongs to the array, not to the Batch: it is released
+        (oalsfx_pinned_free) when the array and every view of it are gone, so an array may outlive close(), and a loop that asks for a
+        fresh array per step holds only what it still references.  (Wait for the calls in flight -- wait() -- before dropping one.)"""
         count = self.n * frames * self.channels
         p = self._lib.oalsfx_pinned_alloc(count * 4)
         if not p:
             raise BatchError("oalsfx_pinned_alloc failed")
         buf = (C.c_float * count).from_address(p)
-        arr = np.frombuffer(buf, dtype=np.float32).reshape(self.n, frames, self.channels)
-        self._pinned = getattr(self, "_pinned", []) + [p]
-        return arr
+        # numpy keeps `buf` alive as the base of the array and of its views; the finalizer holds the library handle
+        weakref.finalize(buf, self._lib.oalsfx_pinned_free, C.c_void_p(p))
+        return np.frombuffer(buf, dtype=np.float32).reshape(self.n, frames, self.channels)
 
     def mix_device(self, frames, src_ptr, dst_ptr, stream=None):
         """Buffers already in device memory (raw addresses, e.g. torch.Tensor.data_ptr()); asynchronous."""

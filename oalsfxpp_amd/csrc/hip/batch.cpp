@@ -12,12 +12,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -138,8 +140,8 @@ struct oalsfx_batch {
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
 
     unsigned long long* d_timeline = nullptr;    // measurement only (OALSFX_DEBUG_TIMELINE=<file>)
-    // Parameter uploads: the changed records are packed into pinned memory, copied in one piece and scattered on the device;
-    // two buffers take turns so that the host never waits for the stream.
+    // Parameter uploads: the changed records are packed into pinned memory and put in place by one kernel (k_upload); four buffers
+    // take turns so that the host never waits for the stream.
     struct Stage { char* host = nullptr; char* dev = nullptr; size_t capacity = 0; hipEvent_t done = nullptr; bool pending = false; };
     Stage stage[4];                               // (four: an event of this stack is seen complete only once the launch behind it has run,
                                                   // so the buffer of two uploads ago would still make the host wait for the GPU)
@@ -302,8 +304,21 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
     struct Candidate { void* p; double us; };
     std::vector<Candidate> cands;
     size_t free_b = 0, total_b = 0;
-    const bool search = bytes >= (static_cast<size_t>(3) << 28) && slab_floats >= 65536 && !(debug_flags() & 0x4000000) &&
-                        hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 > bytes * (static_cast<size_t>(chunks) + 1);
+    // OALSFX_PLACEMENT=0 switches the search off (a process that shares the card with other allocators: the candidates are held until
+    // the search ends); OALSFX_PLACEMENT_MAX_GIB caps what it may hold at once (default: half of the free memory)
+    const char* env_on = std::getenv("OALSFX_PLACEMENT");
+    const char* env_cap = std::getenv("OALSFX_PLACEMENT_MAX_GIB");
+    const bool wanted = bytes >= (static_cast<size_t>(3) << 28) && slab_floats >= 65536 && !(debug_flags() & 0x4000000) && !(env_on && std::atoi(env_on) == 0);
+    // one search at a time in a process: each budgets against the free memory it sees when it starts
+    static std::mutex placement_mutex;
+    std::unique_lock<std::mutex> placement_lock(placement_mutex, std::defer_lock);
+    if (wanted) placement_lock.lock();
+    size_t budget = 0;
+    if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        budget = free_b / 2;
+        if (env_cap && std::atof(env_cap) > 0.0) budget = std::min(budget, static_cast<size_t>(std::atof(env_cap) * 1073741824.0));
+    }
+    const bool search = wanted && budget > bytes * (static_cast<size_t>(chunks) + 1);
     if (!search) {
         for (int k = 0; k < chunks; ++k) {
             void* p = nullptr;
@@ -316,7 +331,7 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
             }
         }
     } else {
-        const size_t max_tries = std::min<size_t>(std::max<size_t>(96, static_cast<size_t>(chunks) * 4), free_b / 2 / bytes);
+        const size_t max_tries = std::min<size_t>(std::max<size_t>(96, static_cast<size_t>(chunks) * 4), budget / bytes);
         const int waves_per_slab = std::max(1, 4096 / count); // a full load (4096 wavefronts) whatever the chunk's size
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (!b->hip_ok(hipEventCreate(&e0), "hipEventCreate") || !b->hip_ok(hipEventCreate(&e1), "hipEventCreate")) return false;
@@ -363,11 +378,8 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
     return true;
 }
 
-// Folds all pending property changes into descriptors, device state and the launch plan: what the
-// reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
-// plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
-// Pinned staging buffer for one round of parameter uploads (two take turns; a buffer is reused only after the copy that
-// read it has completed, which by then is two rounds old).
+// Pinned staging buffer for one round of parameter uploads: four take turns, and a buffer is reused only once the launch that
+// read it has run.
 oalsfx_batch::Stage* acquire_stage(oalsfx_batch* b, size_t bytes)
 {
     // the first buffer, oldest first, whose launch has run (a query: waiting for an event, however old, makes the host wait for
@@ -645,11 +657,16 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // fused runs of reverb-free slots (one launch per slot; config 3: 118.4 against 107.5 us per step), 0x10000000 small parameter
 // uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step), 0x20000000 the
 // caller's stream takes a slot's first part instead of its general kernel
-int g_debug_flags = -1;
+std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
 {
-    if (g_debug_flags < 0) g_debug_flags = std::getenv("OALSFX_DEBUG_FLAGS") ? static_cast<int>(std::strtol(std::getenv("OALSFX_DEBUG_FLAGS"), nullptr, 0)) : 0; // decimal or 0x...
-    return g_debug_flags;
+    int f = g_debug_flags.load(std::memory_order_relaxed);
+    if (f < 0) {
+        const char* env = std::getenv("OALSFX_DEBUG_FLAGS");
+        f = env ? static_cast<int>(std::strtol(env, nullptr, 0)) & 0x7FFFFFFF : 0; // decimal or 0x...
+        g_debug_flags.store(f, std::memory_order_relaxed);
+    }
+    return f;
 }
 
 // Brackets one kernel launch with events recorded on its stream.  (Events attached to the launch itself through
@@ -1225,8 +1242,13 @@ int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, f
     return mix_device(b, frames, src_dev, dst_dev, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream) ? 1 : 0;
 }
 
-int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host)
+namespace {
+
+// Api::mix from host buffers: copy in, kernels, copy out on the batch's stream, then wait.  legs_us (may be null): the three legs as
+// HIP events on that stream saw them.
+int mix_host(oalsfx_batch* b, int frames, const float* src_host, float* dst_host, double* legs_us)
 {
+    if (legs_us) legs_us[0] = legs_us[1] = legs_us[2] = 0.0;
     if (frames == 0) return 1;
     if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
     if (!src_host) return b->fail(kErrNoSrc) ? 1 : 0;
@@ -1241,12 +1263,35 @@ int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* 
         if (!b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_io_dst), floats * sizeof(float)), "hipMalloc(io)")) return 0;
         b->io_capacity = floats;
     }
+    hipEvent_t ev[4] = {};
+    if (legs_us)
+        for (auto& e : ev) e = b->take_event();
+    if (legs_us) hipEventRecord(ev[0], b->stream);
     if (!b->hip_ok(hipMemcpyAsync(b->d_io_src, src_host, floats * sizeof(float), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(src)")) return 0;
+    if (legs_us) hipEventRecord(ev[1], b->stream);
     if (!mix_device(b, frames, b->d_io_src, b->d_io_dst, b->stream)) return 0;
+    if (legs_us) hipEventRecord(ev[2], b->stream);
     if (!b->hip_ok(hipMemcpyAsync(dst_host, b->d_io_dst, floats * sizeof(float), hipMemcpyDeviceToHost, b->stream), "hipMemcpyAsync(dst)")) return 0;
+    if (legs_us) hipEventRecord(ev[3], b->stream);
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    if (legs_us) {
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.0F;
+            if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess) legs_us[k] = ms * 1e3;
+        }
+        for (auto& e : ev) b->event_pool.push_back(e);
+    }
     poll_exact(b);
     return check_fault(b) ? 1 : 0;
+}
+
+} // namespace
+
+int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host) { return mix_host(b, frames, src_host, dst_host, nullptr); }
+
+int oalsfx_batch_mix_timed(oalsfx_batch* b, int frames, const float* src_host, float* dst_host, double legs_us[3])
+{
+    return mix_host(b, frames, src_host, dst_host, legs_us);
 }
 
 int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, float* dst_host)
@@ -1587,7 +1632,7 @@ unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int 
     return reinterpret_cast<unsigned long long>(b->h_rings[static_cast<size_t>(instance) * b->slots + slot]);
 }
 
-void oalsfx_debug_set_flags(int flags) { g_debug_flags = flags < 0 ? 0 : flags; }
+void oalsfx_debug_set_flags(int flags) { g_debug_flags.store(flags < 0 ? 0 : flags, std::memory_order_relaxed); }
 
 int oalsfx_debug_hbm_sweep(int device_id, unsigned long long bytes, int write, int repeats)
 {

@@ -1788,7 +1788,7 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
         }
         if (short_taps) OALSFX_STEADY(2, 4, false, true, true, true, false, true);
         if (modulated) OALSFX_STEADY(2, 4, false, true, true, false, false, true);
-        if (c.timeline) OALSFX_STEADY(2, 4, true, false, false, false, false, true);
+        if (c.timeline && !close_taps) OALSFX_STEADY(2, 4, true, false, false, false, false, true); // (a plain build: no fallback for close taps in an FP launch)
         if (close_taps) OALSFX_STEADY(2, 4, false, true, false, false, false, true);
         OALSFX_STEADY(2, 4, false, false, false, false, false, true);
     }

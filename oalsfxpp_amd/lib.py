@@ -32,6 +32,7 @@ SIGNATURES = {
     "oalsfx_batch_get_send_props": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(desc.SendProps)]),
     "oalsfx_batch_apply_changes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "oalsfx_batch_mix": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "oalsfx_batch_mix_timed": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, C.POINTER(C.c_double)]),
     "oalsfx_batch_mix_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "oalsfx_batch_synchronize": (C.c_int, [C.c_void_p]),
     "oalsfx_batch_mix_async": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),

@@ -188,3 +188,33 @@ class OracleShadow:
         _, sst = self.batch.read_source(self.instance)
         diffs += struct_diff(sst, self.oracle.source_state(), "source_state")
         return diffs
+
+
+class ShadowArmy:
+    """One CPU oracle per listed instance of a `Batch` (all of them by default), mixed on a thread pool: the oracle's entry
+    points are plain C calls, which ctypes runs without the interpreter lock.  For checks that follow *every* instance of a
+    full-size batch instead of a sample."""
+
+    def __init__(self, batch, instances=None, threads=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.batch = batch
+        self.instances = list(range(batch.n)) if instances is None else list(instances)
+        self.shadows = [OracleShadow(batch, i) for i in self.instances]
+        self.pool = ThreadPoolExecutor(max_workers=threads or min(16, len(os.sched_getaffinity(0))))
+
+    def sync(self):
+        for s in self.shadows:
+            s.sync()
+
+    def mix(self, x):
+        """x: the batch's whole input [n][frames][channels]; returns the oracle outputs of the followed instances, in list order."""
+        self.sync()   # (descriptor read-backs are HIP calls: kept on the calling thread)
+        return np.stack(list(self.pool.map(lambda s: s.oracle.mix(x[s.instance]), self.shadows)))
+
+    def differing(self, y, ref):
+        """Followed instances whose device output `y[instance]` differs from the oracle's `ref[k]`: [(instance, samples differing)]."""
+        got = np.ascontiguousarray(y[self.instances]).view(np.uint32)
+        want = np.ascontiguousarray(ref).view(np.uint32)
+        nan = np.isnan(y[self.instances]) & np.isnan(ref)
+        bad = ((got != want) & ~nan).reshape(len(self.instances), -1).sum(axis=1)
+        return [(self.instances[k], int(bad[k])) for k in np.nonzero(bad)[0]]

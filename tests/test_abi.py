@@ -52,7 +52,7 @@ def test_struct_sizes_match_the_c_headers():
 
 
 def test_batch_create_fails_loudly_without_a_gpu():
-    import torch
+    torch = pytest.importorskip("torch")
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
     with pytest.raises(BatchError, match="No HIP device"):

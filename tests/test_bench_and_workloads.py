@@ -42,3 +42,28 @@ def test_cpu_baseline_leg_reports_what_the_contract_asks():
         # the restatement does the reference's work: the two rates agree within timing noise of such a short sample
         assert 0.4 < r["value"] / r["port_value"] < 2.5
     assert 1 <= bench.usable_cores() <= 16
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_never_mislabels():
+    """`python bench.py --gpus 2` with no launcher: the parent (no torch, no HIP) starts two rank processes with the rendezvous
+    variables set.  Without the GPUs the ranks refuse, the parent exits non-zero and no JSON line is printed -- where round 2's
+    script would have benchmarked one GPU and labelled it n_gpus 1."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered on the GPU box by tests/test_gpu_async_and_ranks.py::test_bench_gpus_2_without_a_launcher")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "2 ranks on this node but only 0 GPUs visible" in r.stderr
+    # a rank whose WORLD_SIZE disagrees with --gpus refuses as well
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -139,3 +139,25 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
         want = dst.cpu().numpy()
     for r in range(2):
         assert got[r].tobytes() == want[r * 64 * 512:(r + 1) * 64 * 512].tobytes(), f"rank {r}: outputs differ from the single-process run"
+
+
+def test_bench_gpus_2_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its own two rank processes (before it touches torch
+    or HIP) and relays rank 0's line; it never benchmarks one GPU under a --gpus 2 label.  gloo between the ranks because both share
+    the one GPU here; with the default backend the same command must refuse instead."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6", "--no-cpu-baseline", "--instances", "64",
+           "--no-config5"]
+    r = subprocess.run(cmd, env=dict(env, OALSFX_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "one line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and [x["rank"] for x in d["config"]["devices"]] == [0, 1] and d["value"] > 0
+    assert d["config"]["parallelism"] == "batch-split x2, no collectives"
+    # one visible GPU, RCCL between the ranks, no per-rank visibility mask: refused, not mislabelled
+    import torch
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert "one GPU visible" in r.stderr

@@ -70,6 +70,52 @@ def test_config3_full_size_four_slots():
     replicas_and_sample(4096, 4, program, [0, 1, 2, 3, 255, 2047, 2048, 4092, 4093, 4094, 4095], buffers=7)
 
 
+def test_config4_every_instance_against_the_oracle():
+    """BASELINE configs[3] at full size with *every* instance followed: 8192 instances, effect type 1 + i % 11, every property random
+    (seed = instance).  The rare paths -- chorus / flanger delays of a few samples, short echo taps, reverbs with short or modulated
+    lines -- are then met wherever the random properties put them, not where a sample happens to look.  Four buffers (the reverbs'
+    start-up cross-fade, the first steady-state calls, the promotion to the proven builds), outputs of all 8192; effect state and
+    delay lines for every 37th instance and the last eleven."""
+    import random
+    from harness import ShadowArmy
+    from oalsfxpp_amd.workloads import config4_type, random_effect
+    n = 8192
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [random_effect(random.Random(i), config4_type(i)) for i in range(n)])
+        b.apply_changes()
+        army = ShadowArmy(b)
+        rng = np.random.default_rng(11)
+        for k in range(4):
+            x = rng.uniform(-1, 1, size=(n, 256, 2)).astype(np.float32)
+            y = b.mix(x)
+            bad = army.differing(y, army.mix(x))
+            assert not bad, f"buffer {k}: {len(bad)} instances differ, first (instance, samples): {bad[:6]}, types {[config4_type(i) for i, _ in bad[:6]]}"
+        for s in army.shadows[::37] + army.shadows[-11:]:
+            d = s.compare_state()
+            assert not d, f"instance {s.instance} (type {config4_type(s.instance)}): " + "; ".join(d[:4])
+
+
+def test_config3_every_instance_against_the_oracle():
+    """BASELINE configs[2] at full size, every instance on its own input (the replica check above feeds most of them the same one):
+    4096 x (chorus, flanger, echo, EAX reverb), three buffers, all outputs; state and delay lines of every 64th instance."""
+    from harness import ShadowArmy
+    n = 4096
+    with Batch(n, desc.FMT_STEREO, 48000, 4) as b:
+        for slot, t in enumerate((desc.CHORUS, desc.FLANGER, desc.ECHO, desc.EAX_REVERB)):
+            b.set_effect_type(slot, t)
+        b.apply_changes()
+        army = ShadowArmy(b)
+        rng = np.random.default_rng(12)
+        for k in range(3):
+            x = rng.uniform(-1, 1, size=(n, 256, 2)).astype(np.float32)
+            y = b.mix(x)
+            bad = army.differing(y, army.mix(x))
+            assert not bad, f"buffer {k}: {len(bad)} instances differ, first (instance, samples): {bad[:6]}"
+        for s in army.shadows[::64]:
+            d = s.compare_state()
+            assert not d, f"instance {s.instance}: " + "; ".join(d[:4])
+
+
 class BatchAsApi:
     """The call surface tests/golden/generate.run_case drives, on a two-instance Batch (both instances get every call)."""
 

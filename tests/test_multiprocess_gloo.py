@@ -6,9 +6,11 @@ import socket
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
 
 from oalsfxpp_amd import sharding
 
