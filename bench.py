@@ -245,7 +245,7 @@ def spawn_ranks(n_ranks):
     procs = []
     for rank in range(n_ranks):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OALSFX_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if rank == 0 else subprocess.DEVNULL))
     status = 0
@@ -305,11 +305,11 @@ def main():
     # (HIP_VISIBLE_DEVICES), that one is device 0
     visible = torch.cuda.device_count()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    if distributed and backend == "nccl" and visible < local_world and visible != 1:
-        raise SystemExit(f"--gpus {args.gpus}: {local_world} ranks on this node but only {visible} GPUs visible (one process per GPU)")
-    if distributed and backend == "nccl" and visible == 1 and not (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")):
-        raise SystemExit(f"--gpus {args.gpus}: one GPU visible and no per-rank visibility mask: {local_world} ranks would share it "
-                         "(OALSFX_DIST_BACKEND=gloo rehearses that on purpose)")
+    # (a launcher that narrows every rank's visibility to its own GPU leaves one visible device per rank: trusted; this script's own
+    # ranks all inherit the same mask)
+    if distributed and backend == "nccl" and visible < local_world and (visible != 1 or os.environ.get("OALSFX_BENCH_SELF_LAUNCHED")):
+        raise SystemExit(f"--gpus {args.gpus}: {local_world} ranks on this node but only {visible} GPUs visible (one process per GPU; "
+                         "OALSFX_DIST_BACKEND=gloo rehearses ranks that share a GPU on purpose)")
     local_rank = local_rank % visible if visible > 0 else local_rank
     torch.cuda.set_device(local_rank)
     if distributed:

@@ -160,4 +160,4 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     if torch.cuda.device_count() == 1:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert "one GPU visible" in r.stderr
+        assert "2 ranks on this node but only 1 GPUs visible" in r.stderr
