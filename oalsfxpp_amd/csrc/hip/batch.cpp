@@ -66,6 +66,8 @@ struct oalsfx_batch {
     std::vector<uint8_t> slot_class;              // [n*slots] kClass* bits of the slot's current parameters
     std::vector<size_t> settling;                 // reverb slots updated less than kSettleFrames ago
     std::vector<uint8_t> in_settling;             // [n*slots] membership flag of `settling`
+    std::vector<uint8_t> xf_ok;                   // [n*slots] settling, and in a way the cross-fading build of the steady-state kernel follows
+                                                  // (taps of both sets a tile away, state kept): listed with the believed-steady instances
     int n_close[OALSFX_MAX_SLOTS] = {};           // per slot: reverbs with a tap between one and two tiles ...
     int n_short[OALSFX_MAX_SLOTS] = {};           // ... with a tap shorter than one tile
     bool modulated[OALSFX_MAX_SLOTS] = {};        // some reverb of the slot has, or had, a modulated late line (sticky: the depth
@@ -262,7 +264,31 @@ uint8_t classify_slot(const oalsfx_slot_params& sp)
 // from the real state and falls back by itself).
 bool reverb_settled(const oalsfx_batch* b, size_t idx)
 {
-    return (b->slot_class[idx] & kClassSteady) != 0 && b->since_update[idx] >= kSettleFrames;
+    return (b->slot_class[idx] & kClassSteady) != 0 && (b->since_update[idx] >= kSettleFrames || b->xf_ok[idx]);
+}
+
+// Can the cross-fading build (reverb.hip, XF) take an instance from parameters `from` to parameters `to`?  Both tap sets must be ones
+// the most general steady-state build accepts (classify_slot), the late taps counted from the *new* late feed position and the late
+// line given the sway of whichever modulation is deeper.  A hint like the rest: the kernel checks against the device state and falls
+// back by itself.
+bool crossfade_followable(const oalsfx_reverb_params& from, const oalsfx_reverb_params& to)
+{
+    const int sway = (from.mod_depth != 0.0F || to.mod_depth != 0.0F) ? 1 + static_cast<int>(std::max(std::abs(from.mod_depth), std::abs(to.mod_depth))) : 0;
+    for (const oalsfx_reverb_params* p : {&from, &to})
+        for (int j = 0; j < 4; ++j)
+            if (p->early_tap[j] < 0 || p->early_ap_off[j] < 16 || p->early_line_off[j] < 64 || p->late_tap[j] < to.late_feed_tap ||
+                p->late_ap_off[j] < 16 || p->late_line_off[j] < 64 + sway)
+                return false;
+    return true;
+}
+
+// Is some reverb of the slot in a transition the cross-fading build follows?  (`settling` is short: the instances updated within the
+// last 128 frames.)
+bool slot_in_transition(const oalsfx_batch* b, int slot)
+{
+    for (size_t idx : b->settling)
+        if (static_cast<int>(idx % b->slots) == slot && b->xf_ok[idx]) return true;
+    return false;
 }
 
 void reclassify_slot(oalsfx_batch* b, size_t idx, int slot)
@@ -283,6 +309,7 @@ void advance_settling(oalsfx_batch* b, int frames)
         b->since_update[idx] = std::min(b->since_update[idx] + frames, kSettleFrames);
         if (b->since_update[idx] < kSettleFrames) { b->settling[keep++] = idx; continue; }
         b->in_settling[idx] = 0;
+        b->xf_ok[idx] = 0;
         if (b->slot_class[idx] & kClassSteady) { b->lists_dirty = true; b->exact_wanted = true; }
     }
     b->settling.resize(keep);
@@ -440,11 +467,16 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
             updated = true;
             const size_t idx = static_cast<size_t>(i) * b->slots + s;
             oalsfx_slot_params& p = b->h_params[idx];
+            // a settled reverb whose properties change without a change of type keeps its state and cross-fades: what the XF build follows
+            const bool was_settled = (b->slot_class[idx] & kClassSteady) != 0 && b->since_update[idx] >= kSettleFrames && !h.slot_retyped[s];
+            const oalsfx_reverb_params before = p.u.reverb;
             derive_slot(b->dev, h.active[s], p);
             p.update_seq = ++b->seq[idx];
             up_params.push_back(static_cast<int>(idx));
             reclassify_slot(b, idx, s);
-            if (b->since_update[idx] >= kSettleFrames) b->lists_dirty = true; // it leaves the believed-steady part of its list
+            b->xf_ok[idx] = was_settled && (b->slot_class[idx] & kClassSteady) != 0 && b->channels <= 2 && !(debug_flags() & 0x40000000) &&
+                            crossfade_followable(before, p.u.reverb);
+            b->lists_dirty = true; // (it leaves the proven part of its list, or the steady part altogether)
             b->since_update[idx] = 0;
             if ((b->slot_class[idx] & kClassReverb) && !b->in_settling[idx]) {
                 b->in_settling[idx] = 1;
@@ -656,7 +688,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // (exercises the fault counter of the FP builds: tests only), 0x4000000 no placement search for the delay-line chunks, 0x8000000 no
 // fused runs of reverb-free slots (one launch per slot; config 3: 118.4 against 107.5 us per step), 0x10000000 small parameter
 // uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step), 0x20000000 the
-// caller's stream takes a slot's first part instead of its general kernel
+// caller's stream takes a slot's first part instead of its general kernel, 0x40000000 no cross-fading build: reverbs whose properties
+// change go to the general kernel for 128 frames, as before round 3
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
 {
@@ -720,7 +753,7 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
         const char* name = oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0,
-                                                            b->modulated[slot], b->n_short[slot] > 0, proven, stream);
+                                                            b->modulated[slot], b->n_short[slot] > 0, proven, !proven && slot_in_transition(b, slot), stream);
         if (name) b->last_steady_kernel = name;
     }
     if (hand_over && count > lead) {
@@ -1039,6 +1072,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->since_update.assign(total, 0);
     b->slot_class.assign(total, 0);
     b->in_settling.assign(total, 0);
+    b->xf_ok.assign(total, 0);
     b->proven.assign(total, 0);
     b->updated_gen.assign(total, 0);
     b->inst_epoch.assign(n_instances, 1); // a zero-filled hot record never carries a valid stamp

@@ -103,9 +103,11 @@ constexpr int kWave = 64;
 // a modulated late line, which selects the build that carries the modulation; short_taps: some listed instance has a tap
 // shorter than one tile, which selects the most general build.
 // proven: the host has device-confirmed knowledge that every listed instance is steady (mono / stereo, whole tiles): the FP builds.
+// in_transition: some listed instance had its properties changed less than a cross-fade ago, in a way the XF build can follow (mono /
+// stereo, whole tiles, not proven): that build.
 // Returns the kernel symbol it launched (template arguments as rocprofv3 prints them), nullptr when the list was empty.
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated,
-                                 bool short_taps, bool proven, hipStream_t stream);
+                                 bool short_taps, bool proven, bool in_transition, hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments

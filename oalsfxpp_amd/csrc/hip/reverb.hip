@@ -229,6 +229,8 @@ namespace coop {
 enum { LPX0, LPX1, LPY0, LPY1, HPY0, HPY1, T60X, T60O1, T60O2, LP_A1, LP_A2, HP_A1, HP_A2, T_L2, T_H2, T_MID, SIZE };
 }
 
+__device__ __forceinline__ int wib_of(unsigned tid) { return __builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6)); }
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -247,6 +249,12 @@ __device__ __forceinline__ void lds_barrier()
 // the dry mix and the panning loop over the channels, and an instance that is not steady is not taken inside the kernel
 // (its LDS would have to be sized for the general path's 64 gain ramps) but left, through ctx.progress, to the general
 // kernel that the host launches right after on the same list (any build works that way when ctx.progress is set).
+// XF (a variant of the ST build, mono / stereo, whole tiles, not FP): an instance whose properties were changed stays in the cooperative
+// workgroup while it cross-fades its taps and ramps its output gains (reference src/oalsfxpp.cpp:6062-6075, 6088-6096, 6118-6138,
+// 7378-7399, 2752-2798) -- provided both tap sets are ones the ST build accepts and the fade stands at a tile boundary.  Its
+// cross-fading tiles request the taps being faded in at the top of the tile, behind the previous tile's stores, and mix the two sets
+// per sample (where a set's source lies inside the tile, after that set's own hand-over); the gains that ramp are stepped serially (the running sum is not a closed form in
+// floating point) by the wavefront's own lanes, one per gain, into rows of the late half that are idle in S5.
 // RG (a variant of the ST build): calls that are not a whole number of tiles.  The last tile holds L < 64 samples: its lanes
 // from L on compute along but store nothing, the recurrences and the modulation smoother stop at L, and the histories are
 // taken from sample L - 1.
@@ -267,6 +275,7 @@ struct SteadyShared {
                                       : (Lds<CH>::kFloats > kSteadyFloats ? Lds<CH>::kFloats : kSteadyFloats);
     alignas(16) float lds_all[NW][kFloats];
     float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
+    unsigned tapn_all[FP ? 1 : NW][24]; // XF: [wave][group * 4 + line]: the taps being faded in, as byte distances like ut::TAP4
     int go_all[NW];
     int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
 };
@@ -278,11 +287,14 @@ struct SteadyShared {
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
 // kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, class SH>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
 {
     static_assert(!FP || (CH <= 2 && !RG), "the proven-steady builds: mono / stereo, whole tiles");
+    static_assert(!XF || (CH <= 2 && !RG && !FP && HY && MD && ST), "the cross-fading build: a variant of the most general one, mono / stereo, whole tiles");
+    // XF: dword offset (from the table) of the taps being faded in: a second tap table with ut::TAP4's layout, in the workgroup's own array
+    const int kTapN = static_cast<int>(reinterpret_cast<float*>(&sh.tapn_all[FP ? 0 : wib_of(threadIdx.x)][0]) - (sh.lds_all[wib_of(threadIdx.x)] + kSteadyGroups * 4 * kRow));
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
     int ts_i = 0;
     auto stamp = [&]() {
@@ -336,6 +348,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned epoch_now = 0;
     unsigned* miscu = reinterpret_cast<unsigned*>(utf + (FP ? SH::kFpMisc : 0)); // FP: image of the record's MISC block
     bool hit = false;
+    // XF: an instance that folds in a property change, cross-fades or ramps gains in this call
+    bool xf_active = false;
+    int fc0 = OALSFX_RV_FADE_SAMPLES; // its fade count at the start of the call (after a pending change has been folded in)
+    float g_cur = 0.0F, g_tgt = 0.0F;  // lane q < 8 * CH: an output gain and its target
     float early_in0 = 0.0F, early_in1 = 0.0F; // FP: the first tile's frame, requested beside the hot record
     float hist_new[2] = {0.0F, 0.0F}, hist_old[2] = {0.0F, 0.0F}; // FP: the call's last two frames per channel, for the send filters' histories
     if constexpr (FP) {
@@ -399,6 +415,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     const int v_offset = S.offset;
     v_modidx = S.mod_index; v_modrange = S.mod_range;
     const int v_tap = (&S.cur_early_tap[0])[min(lane, 23)];
+    int v_newtap = 0; // XF: the taps a change would fade in (the six arrays are not adjacent in the parameter block)
+    if (XF) {
+        const int g = min(lane >> 2, 5);
+        const int32_t* from = g == 0 ? PG.early_tap : g == 1 ? PG.early_ap_off : g == 2 ? PG.early_line_off : g == 3 ? PG.late_tap : g == 4 ? PG.late_ap_off : PG.late_line_off;
+        v_newtap = from[l4];
+    }
     const int v_ring_off = PG.ring_off[min(lane >> 2, 4)], v_ring_len = PG.ring_len[min(lane >> 2, 4)];
     const int v_ring_len5 = PG.ring_len[min(lane, 4)];
     const float v_gcur = q_valid ? (q_stage ? S.late_cur_gain[q_line][q_chan] : S.early_cur_gain[q_line][q_chan]) : 0.0F;
@@ -415,34 +437,50 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     const float v_gaux = MC ? SG.aux[slot].gains[(lane >> 2) & 7][lane & 3] : SG.aux[slot].gains[(lane >> 2) & 1][lane & 3];
     mod_depth = P.mod_depth; mod_coeff = P.mod_coeff;
     mod_f = v_modf;
+    bool xf_pending = false;
+    if constexpr (XF) {
+        xf_pending = v_seen != SP.update_seq;
+        fc0 = v_fade;
+        if (xf_pending) {
+            // what the reference's update does to the state (src/oalsfxpp.cpp:7028-7031, 6062-6075): the modulator's index follows its
+            // new range, and taps that moved start a cross-fade
+            v_modidx = static_cast<int>(static_cast<long long>(v_modidx) * P.mod_range / v_modrange);
+            v_modrange = P.mod_range;
+            if (__ballot(lane < 24 && v_newtap != v_tap) != 0ULL) fc0 = 0;
+        }
+    }
+    const bool fading = XF && fc0 < OALSFX_RV_FADE_SAMPLES;
 
-    // ---- is this instance in its steady state for the whole buffer? ----
-    go = valid && (RG || (frames & 63) == 0) && (v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES) &&
+    // ---- is this instance in its steady state for the whole buffer?  (XF: or in a state the cross-fading tiles handle) ----
+    go = valid && (RG || (frames & 63) == 0) && (XF ? (!fading || (fc0 & 63) == 0) : ((v_seen == SP.update_seq) && (v_fade >= OALSFX_RV_FADE_SAMPLES))) &&
          (MD || ((P.mod_depth == 0.0F) && (v_modf == 0.0F)));
     mod_on = MD && ((P.mod_depth != 0.0F) || (v_modf != 0.0F));
-    const float g_cur = v_gcur;
+    g_cur = v_gcur; g_tgt = v_gtgt;
     {
         // the last chunk of the buffer has the smallest ramp counter, hence the largest step: no ramp there, no ramp anywhere
         const int last_chunk = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
         const float step = (v_gtgt - g_cur) * (1.0F / static_cast<float>(last_chunk));
-        if (__ballot(q_valid && fabsf(step) > FLT_EPSILON) != 0ULL) go = false;
+        const bool ramping = __ballot(q_valid && fabsf(step) > FLT_EPSILON) != 0ULL;
+        if (ramping && !XF) go = false;
+        xf_active = XF && (xf_pending || fading || ramping); // (a fade splits the call into other blocks than these: the XF tiles step block by block)
         // every tap at least two tiles away from its write position (late taps: from the late feed position); the hybrid
         // build accepts one tile and requests the groups that are closer than two at the top of their own tile
         const unsigned tp = (lane < 24) ? 4u * static_cast<unsigned>(v_tap) : 0xFFFFFFFFu;
+        const unsigned tpn = (fading && lane < 24) ? 4u * static_cast<unsigned>(v_newtap) : 0xFFFFFFFFu; // XF: the taps being faded in must keep their distance too
         unsigned feed4 = (lane >> 2) == 3 ? 4u * static_cast<unsigned>(P.late_feed_tap) : 0u;
         // a modulated late line reads up to |depth| samples closer (the smoother moves monotonically towards the depth)
         if (MD && (lane >> 2) == 5) feed4 = 4u * (1u + static_cast<unsigned>(fmaxf(fabsf(P.mod_depth), fabsf(v_modf))));
         const int grp = lane >> 2;
         // shortest distance accepted per group: early / late taps any, all-pass offsets a quarter tile (ST build only)
         const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 64u : 256u;
-        if (__ballot(tp >= shortest + feed4) != ~0ULL) go = false;
+        if (__ballot(tp >= shortest + feed4 && tpn >= shortest + feed4) != ~0ULL) go = false;
         if (ST) {
-            const unsigned long long in_tile = __ballot(lane < 24 && tp < 256u + feed4);
+            const unsigned long long in_tile = __ballot(lane < 24 && (tp < 256u + feed4 || tpn < 256u + feed4));
 #pragma unroll
             for (int g = 0; g < 6; ++g) short_mask |= ((in_tile >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
         if (HY) {
-            const unsigned long long close = __ballot(tp < 512u + feed4);
+            const unsigned long long close = __ballot(tp < 512u + feed4 || tpn < 512u + feed4);
 #pragma unroll
             for (int g = 0; g < 6; ++g) late_mask |= ((close >> (4 * g)) & 0xFULL) ? 1u << g : 0u;
         }
@@ -451,7 +489,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // outside the lane-0 branch.)
         if (!FP && ctx.exact) {
             const unsigned level = gains_rest_level(q_valid, g_cur, v_gtgt);
-            if (valid && go && lane == 0) ctx.exact[sidx] = level;
+            if (valid && go && lane == 0 && !xf_active) ctx.exact[sidx] = level; // (an instance in transition reports at the end of the call)
         }
     }
     eax = P.is_eax != 0; // plain reverb and EAX reverb instances may share a workgroup
@@ -464,6 +502,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // ---- per-wave table of instance constants in LDS (see namespace ut), chain data per line ----
         // (flags >> 8) & 32 / 64: timing experiment only (OALSFX_DEBUG_FLAGS), taps rounded to 128 / 256 bytes, results wrong
         if (lane < 24) utu[ut::TAP4 + lane] = (4u * static_cast<unsigned>(v_tap)) & ((flags & (64 << 8)) ? ~255u : (flags & (32 << 8)) ? ~127u : ~0u);
+        if (XF && lane < 24) utu[kTapN + lane] = 4u * static_cast<unsigned>(v_newtap);
         if (lane < 20) utu[ut::LO + lane] = static_cast<unsigned>(v_ring_off + l4 * v_ring_len) << 2;
         if (lane < 5) utu[ut::BMASK + lane] = static_cast<unsigned>(v_ring_len5 - 1) << 2;
         if (lane < 4) {
@@ -553,8 +592,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     float n_inv[MC ? 8 : 1] = {}; // multichannel: the frame's input channels
     float n_w0 = 0.0F, n_w1 = 0.0F;
     float n_wv[MC ? 8 : 1] = {};
-    auto load4 = [&](unsigned t4x, int group, int r) -> v4f {
-        const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+    // XF: which tap table is current in a tile: the one being faded in once the fade is through
+    auto tapbase = [&](int tile) -> int { return (XF && fc0 < OALSFX_RV_FADE_SAMPLES && fc0 + (tile << 6) >= OALSFX_RV_FADE_SAMPLES) ? kTapN : static_cast<int>(ut::TAP4); };
+    auto load4 = [&](unsigned t4x, int group, int r, int base = ut::TAP4) -> v4f {
+        const v4u d = *reinterpret_cast<const v4u*>(utu + base + 4 * group);
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
         const unsigned bm = utu[ut::BMASK + r];
         v4f v;
@@ -615,17 +656,17 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
     };
     // the ring requests of a tile in three parts (S1, S3, S5 of the iteration before its late half)
-    auto issue_taps_a = [&](unsigned t4x) {
-        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN);
-        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP);
+    auto issue_taps_a = [&](unsigned t4x, int base) {
+        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN, base);
+        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP, base);
     };
-    auto issue_taps_b = [&](unsigned t4x) {
-        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE);
-        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN);
-        if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE);
+    auto issue_taps_b = [&](unsigned t4x, int base) {
+        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE, base);
+        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN, base);
+        if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE, base);
     };
-    auto issue_taps_c = [&](unsigned t4x) {
-        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP);
+    auto issue_taps_c = [&](unsigned t4x, int base) {
+        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP, base);
     };
     auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
@@ -646,7 +687,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if (go) {
         if (FP && !(flags & kFiltered)) { n_in0 = early_in0; n_in1 = early_in1; }
         else issue_input(lane);
-        issue_taps_a(static_cast<unsigned>(offset + lane) << 2);
+        issue_taps_a(static_cast<unsigned>(offset + lane) << 2, tapbase(0));
     }
     stamp(); // [3] first requests issued
     lds_barrier(); // tables, chain data and go flags are in place
@@ -669,6 +710,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // ring requests travel.  The shelves' output of tile it waits in its own rows (rowI) for the next iteration's P3.
     float o0 = 0.0F, o1 = 0.0F;
     float outv[MC ? 8 : 1] = {}; // multichannel: the output frame being accumulated (of the tile whose late half runs)
+    // XF: the blocks of an instance in transition (reference ReverbEffectState::do_process, src/oalsfxpp.cpp:6088-6096): at most 256 frames,
+    // cut where a cross-fade ends; every block takes a new step for each output gain (MixHelpers::mix, src/oalsfxpp.cpp:2752-2798)
+    int fc = fc0, blk_start = 0, blk_end = 0, blk_counter = 1;
+    float g_step = 0.0F, g_run = 0.0F;
+    bool g_ramp = false;
+    unsigned long long ramp_mask = 0ULL;
+    // ... and where the stepped gains of a tile go: rows of the late half that are idle in S5, and hand-over rows
+    auto grow = [&](int q) -> float* { return q < 12 ? rowL(q >> 2, q & 3) + 4 : utf + ut::SIZE + (2 + q - 12) * kRow + 4; };
     for (int it = 0; it <= tiles && tiles > 0; ++it) {
         const int ta = it, tb = it - 1;
         const bool has_a = ta < tiles, has_b = tb >= 0;
@@ -684,6 +733,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         float outva[MC ? 8 : 1] = {}; // the dry mix (or the running mix of the slots before) of tile ta
         v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
         const int xg = eax ? 0 : 2; // where the shelves left their output
+        // XF: is the late half's tile one in which the taps are cross-faded?  mu: how far, per sample; q_*: the taps being faded in
+        const bool xf_faded = XF && xf_active && has_b && fc0 + (tb << 6) < OALSFX_RV_FADE_SAMPLES;
+        const float mu = static_cast<float>(fc0 + pos_b) * (1.0F / OALSFX_RV_FADE_SAMPLES);
+        v4f q_e = {0, 0, 0, 0}, q_a = q_e, q_lt = q_e;
+        auto mix4 = [&](v4f& a, const v4f& b) {
+            a.x = lerpf(a.x, b.x, mu); a.y = lerpf(a.y, b.y, mu); a.z = lerpf(a.z, b.z, mu); a.w = lerpf(a.w, b.w, mu);
+        };
+        const int tb_base = tapbase(tb); // the tap table that is current in the late half's tile
 
         if (go) {
             if (MD) {
@@ -692,16 +749,26 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             }
             if (HY && has_b) {
                 // groups with a tap closer than two tiles: requested now, after the previous tile's stores
-                if (late_mask & 1u) p_e = load4(t4, 0, OALSFX_RV_MAIN);
-                if (late_mask & 2u) p_a = load4(t4, 1, OALSFX_RV_EARLY_AP);
-                if (late_mask & 4u) p_el = load4(t4, 2, OALSFX_RV_EARLY_LINE);
-                if (late_mask & 8u) p_lt = load4(t4, 3, OALSFX_RV_MAIN);
-                if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP);
-                if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE);
+                const int base = tapbase(tb);
+                if (late_mask & 1u) p_e = load4(t4, 0, OALSFX_RV_MAIN, base);
+                if (late_mask & 2u) p_a = load4(t4, 1, OALSFX_RV_EARLY_AP, base);
+                if (late_mask & 4u) p_el = load4(t4, 2, OALSFX_RV_EARLY_LINE, base);
+                if (late_mask & 8u) p_lt = load4(t4, 3, OALSFX_RV_MAIN, base);
+                if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP, base);
+                if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE, base);
+            }
+            if (XF && xf_faded) {
+                // a cross-fading tile (reference delay_out_faded, src/oalsfxpp.cpp:7378-7399): the taps being faded in are requested here,
+                // behind the previous tile's stores, and mixed with the current ones sample by sample: the two lines at once (their taps
+                // are a tile away), the others where they are used, behind the hand-over inside the tile that either set may need
+                q_e = load4(t4, 0, OALSFX_RV_MAIN, kTapN); q_a = load4(t4, 1, OALSFX_RV_EARLY_AP, kTapN);
+                q_lt = load4(t4, 3, OALSFX_RV_MAIN, kTapN);
+                const v4f q_el = load4(t4, 2, OALSFX_RV_EARLY_LINE, kTapN), q_ll = load4(t4 - 4u * static_cast<unsigned>(md_cur), 5, OALSFX_RV_LATE_LINE, kTapN);
+                mix4(p_el, q_el); mix4(p_ll, q_ll);
             }
             // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts (top and end of S1, S3): a wavefront
             // that issues all 24 in one go sits in the issue queue while its siblings and its own arithmetic wait
-            if (has_a && it > 0) issue_taps_a(t4 + 256u); // (the prologue issued tile 0's)
+            if (has_a && it > 0) issue_taps_a(t4 + 256u, tapbase(ta)); // (the prologue issued tile 0's)
             __builtin_amdgcn_sched_barrier(0); // keep the requests up here: the scheduler would sink them next to their first use
         }
         // ---------------- S1, late half: P3(tb): main delay write, early reflections, late taps, T60 first feed-forward ----------------
@@ -716,25 +783,37 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             const v4f elc = *reinterpret_cast<const v4f*>(utf + ut::ELCOEF);
             if (ST && (short_mask & 1u)) {
                 // early taps shorter than the tile read what an earlier lane just wrote to the main delay: the shelves' output
-                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4);
-                const int e0 = static_cast<int>(d.x >> 2), e1 = static_cast<int>(d.y >> 2), e2 = static_cast<int>(d.z >> 2), e3 = static_cast<int>(d.w >> 2);
-                if (lane >= e0) p_e.x = rowI(xg, 0)[4 + lane - e0];
-                if (lane >= e1) p_e.y = rowI(xg, 1)[4 + lane - e1];
-                if (lane >= e2) p_e.z = rowI(xg, 2)[4 + lane - e2];
-                if (lane >= e3) p_e.w = rowI(xg, 3)[4 + lane - e3];
+                auto hand_over = [&](v4f& v, int base) {
+                    const v4u d = *reinterpret_cast<const v4u*>(utu + base);
+                    const int e0 = static_cast<int>(d.x >> 2), e1 = static_cast<int>(d.y >> 2), e2 = static_cast<int>(d.z >> 2), e3 = static_cast<int>(d.w >> 2);
+                    if (lane >= e0) v.x = rowI(xg, 0)[4 + lane - e0];
+                    if (lane >= e1) v.y = rowI(xg, 1)[4 + lane - e1];
+                    if (lane >= e2) v.z = rowI(xg, 2)[4 + lane - e2];
+                    if (lane >= e3) v.w = rowI(xg, 3)[4 + lane - e3];
+                };
+                hand_over(p_e, XF ? tb_base : static_cast<int>(ut::TAP4));
+                if (XF && xf_faded) hand_over(q_e, kTapN);
             }
+            if (XF && xf_faded) mix4(p_e, q_e);
             if (ST && (short_mask & 2u)) {
                 // all-pass offsets shorter than the tile: the lanes whose sources lie in earlier tiles are right from the
                 // start; every evaluation ahead of the real one makes the next `shortest offset` lanes right, which then hand
                 // their all-pass ring values to the lanes that read them
-                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4);
+                const v4u d = *reinterpret_cast<const v4u*>(utu + (XF ? tb_base : static_cast<int>(ut::TAP4)) + 4);
                 const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
-                const int ahead = 63 / min(min(o0x, o1x), min(o2x, o3x));
+                int shortest_off = min(min(o0x, o1x), min(o2x, o3x));
+                // XF, a cross-fading tile: the set being faded in hands over by its own offsets
+                const v4u dn = *reinterpret_cast<const v4u*>(utu + (XF ? kTapN : static_cast<int>(ut::TAP4)) + 4);
+                const int n0x = static_cast<int>(dn.x >> 2), n1x = static_cast<int>(dn.y >> 2), n2x = static_cast<int>(dn.z >> 2), n3x = static_cast<int>(dn.w >> 2);
+                if (XF && xf_faded) shortest_off = min(shortest_off, min(min(n0x, n1x), min(n2x, n3x)));
+                const int ahead = 63 / shortest_off;
                 const v2f pf01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
                 const v2f pf23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
                 for (int k = 0; k < ahead; ++k) {
-                    const v2f pv01 = v2f{p_a.x, p_a.y} - (ac * pf01);
-                    const v2f pv23 = v2f{p_a.z, p_a.w} - (ac * pf23);
+                    v4f a_now = p_a;
+                    if (XF && xf_faded) mix4(a_now, q_a);
+                    const v2f pv01 = v2f{a_now.x, a_now.y} - (ac * pf01);
+                    const v2f pv23 = v2f{a_now.z, a_now.w} - (ac * pf23);
                     v2f pg01 = pf01 + (ac * pv01);
                     v2f pg23 = pf23 + (ac * pv23);
                     scatter2(pg01, pg23, sx, sy);
@@ -744,9 +823,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     if (lane >= o1x) p_a.y = strow(1)[4 + lane - o1x];
                     if (lane >= o2x) p_a.z = strow(2)[4 + lane - o2x];
                     if (lane >= o3x) p_a.w = strow(3)[4 + lane - o3x];
+                    if (XF && xf_faded) {
+                        if (lane >= n0x) q_a.x = strow(0)[4 + lane - n0x];
+                        if (lane >= n1x) q_a.y = strow(1)[4 + lane - n1x];
+                        if (lane >= n2x) q_a.z = strow(2)[4 + lane - n2x];
+                        if (lane >= n3x) q_a.w = strow(3)[4 + lane - n3x];
+                    }
                     wave_sync();
                 }
             }
+            if (XF && xf_faded) mix4(p_a, q_a);
             const v2f f01 = v2f{p_e.x, p_e.y} * v2f{ec.x, ec.y};
             const v2f f23 = v2f{p_e.z, p_e.w} * v2f{ec.z, ec.w};
             const v2f v01 = v2f{p_a.x, p_a.y} - (ac * f01);
@@ -768,16 +854,21 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     // late taps closer than a tile to the late feed read what an earlier lane just fed
                     strow(4)[4 + lane] = r01.x; strow(5)[4 + lane] = r01.y; strow(6)[4 + lane] = r23.x; strow(7)[4 + lane] = r23.y;
                     wave_sync();
-                    const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 12);
-                    const unsigned f4 = utu[ut::FEED4];
-                    const int l0 = static_cast<int>((d.x - f4) >> 2), l1 = static_cast<int>((d.y - f4) >> 2), l2 = static_cast<int>((d.z - f4) >> 2),
-                              l3 = static_cast<int>((d.w - f4) >> 2);
-                    if (lane >= l0) p_lt.x = strow(4)[4 + lane - l0];
-                    if (lane >= l1) p_lt.y = strow(5)[4 + lane - l1];
-                    if (lane >= l2) p_lt.z = strow(6)[4 + lane - l2];
-                    if (lane >= l3) p_lt.w = strow(7)[4 + lane - l3];
+                    auto hand_over = [&](v4f& v, int base) {
+                        const v4u d = *reinterpret_cast<const v4u*>(utu + base + 12);
+                        const unsigned f4 = utu[ut::FEED4];
+                        const int l0 = static_cast<int>((d.x - f4) >> 2), l1 = static_cast<int>((d.y - f4) >> 2), l2 = static_cast<int>((d.z - f4) >> 2),
+                                  l3 = static_cast<int>((d.w - f4) >> 2);
+                        if (lane >= l0) v.x = strow(4)[4 + lane - l0];
+                        if (lane >= l1) v.y = strow(5)[4 + lane - l1];
+                        if (lane >= l2) v.z = strow(6)[4 + lane - l2];
+                        if (lane >= l3) v.w = strow(7)[4 + lane - l3];
+                    };
+                    hand_over(p_lt, XF ? tb_base : static_cast<int>(ut::TAP4));
+                    if (XF && xf_faded) hand_over(q_lt, kTapN);
                 }
             }
+            if (XF && xf_faded) mix4(p_lt, q_lt);
             const v2f u01 = (v2f{p_lt.x, p_lt.y} * dg) + v2f{p_ll.x, p_ll.y};
             const v2f u23 = (v2f{p_lt.z, p_lt.w} * dg) + v2f{p_ll.z, p_ll.w};
             if (lane < 4) rowL(0, lane)[3] = chain_all[wib][lane][coop::T60X];
@@ -874,7 +965,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
         if (go && has_a) {
             // (all of a tile's requests at the top of S1, or the late all-pass group here instead of in S3: measured, no faster)
-            issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2); // on their way while the chain phases run
+            issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta)); // on their way while the chain phases run
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
@@ -907,7 +998,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         stamp();
         // ---------------- S3: P2(ta), feed-forward half of the second shelf; P4(tb), second T60 feed-forward ----------------
         if (go && has_a) {
-            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2);
+            issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (any_eax) {
@@ -958,14 +1049,23 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (go && has_b) {
             const v2f i01 = {rowL(1, 0)[4 + lane], rowL(1, 1)[4 + lane]};
             const v2f i23 = {rowL(1, 2)[4 + lane], rowL(1, 3)[4 + lane]};
+            // XF, a cross-fading tile: the late all-pass taps being faded in are requested here (nothing of this tile has touched that ring yet)
+            v4f q_la = {0, 0, 0, 0};
+            if (XF && xf_faded) q_la = load4(t4, 4, OALSFX_RV_LATE_AP, kTapN);
             if (ST && (short_mask & 16u)) {
                 // late all-pass offsets shorter than the tile, as for the early all-pass
-                const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 16);
+                const v4u d = *reinterpret_cast<const v4u*>(utu + (XF ? tb_base : static_cast<int>(ut::TAP4)) + 16);
                 const int o0x = static_cast<int>(d.x >> 2), o1x = static_cast<int>(d.y >> 2), o2x = static_cast<int>(d.z >> 2), o3x = static_cast<int>(d.w >> 2);
-                const int ahead = 63 / min(min(o0x, o1x), min(o2x, o3x));
+                int shortest_off = min(min(o0x, o1x), min(o2x, o3x));
+                const v4u dn = *reinterpret_cast<const v4u*>(utu + (XF ? kTapN : static_cast<int>(ut::TAP4)) + 16);
+                const int n0x = static_cast<int>(dn.x >> 2), n1x = static_cast<int>(dn.y >> 2), n2x = static_cast<int>(dn.z >> 2), n3x = static_cast<int>(dn.w >> 2);
+                if (XF && xf_faded) shortest_off = min(shortest_off, min(min(n0x, n1x), min(n2x, n3x)));
+                const int ahead = 63 / shortest_off;
                 for (int k = 0; k < ahead; ++k) {
-                    const v2f pl01 = v2f{p_la.x, p_la.y} - (ac * i01);
-                    const v2f pl23 = v2f{p_la.z, p_la.w} - (ac * i23);
+                    v4f a_now = p_la;
+                    if (XF && xf_faded) mix4(a_now, q_la);
+                    const v2f pl01 = v2f{a_now.x, a_now.y} - (ac * i01);
+                    const v2f pl23 = v2f{a_now.z, a_now.w} - (ac * i23);
                     v2f pq01 = i01 + (ac * pl01), pq23 = i23 + (ac * pl23);
                     scatter2(pq01, pq23, sx, sy);
                     strow(0)[4 + lane] = pq01.x; strow(1)[4 + lane] = pq01.y; strow(2)[4 + lane] = pq23.x; strow(3)[4 + lane] = pq23.y;
@@ -974,9 +1074,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     if (lane >= o1x) p_la.y = strow(1)[4 + lane - o1x];
                     if (lane >= o2x) p_la.z = strow(2)[4 + lane - o2x];
                     if (lane >= o3x) p_la.w = strow(3)[4 + lane - o3x];
+                    if (XF && xf_faded) {
+                        if (lane >= n0x) q_la.x = strow(0)[4 + lane - n0x];
+                        if (lane >= n1x) q_la.y = strow(1)[4 + lane - n1x];
+                        if (lane >= n2x) q_la.z = strow(2)[4 + lane - n2x];
+                        if (lane >= n3x) q_la.w = strow(3)[4 + lane - n3x];
+                    }
                     wave_sync();
                 }
             }
+            if (XF && xf_faded) mix4(p_la, q_la);
             const v2f l01 = v2f{p_la.x, p_la.y} - (ac * i01);
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
             v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
@@ -1006,13 +1113,59 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                         if (c < nch) mixbuf[c * OALSFX_MAX_CHUNK + pos_b] = outv[MC ? c : 0];
                 }
             }
+            if (XF && xf_active) {
+                const int tpos = tb << 6;
+                if (tpos == blk_end) {
+                    // a block starts with this tile
+                    blk_start = tpos;
+                    int todo = min(frames - tpos, OALSFX_RV_MAX_UPDATE);
+                    if (fc < OALSFX_RV_FADE_SAMPLES) todo = min(todo, OALSFX_RV_FADE_SAMPLES - fc);
+                    blk_end = tpos + todo;
+                    blk_counter = frames - tpos;
+                    g_step = (g_tgt - g_cur) * (1.0F / static_cast<float>(blk_counter));
+                    g_ramp = q_valid && (fabsf(g_step) > FLT_EPSILON);
+                    ramp_mask = __ballot(g_ramp);
+                    g_run = g_cur;
+                }
+                if (ramp_mask != 0ULL) {
+                    if (g_ramp) {
+                        float* gs = grow(lane);
+                        for (int i = 0; i < 64; ++i) {
+                            gs[i] = g_run;
+                            g_run += g_step;
+                        }
+                    }
+                    wave_sync();
+                }
 #pragma unroll
-            for (int k = 0; k < (MC ? 0 : 8); k += 2) {
-                const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k);
-                if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
-                if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
-                if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
-                if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                        const int q = k * CH + c;
+                        float& o = c == 0 ? o0 : o1;
+                        if ((ramp_mask >> q) & 1ULL) {
+                            o += data[k] * grow(q)[lane];
+                        } else {
+                            const float gq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(g_cur), q));
+                            if (audible(gq)) o += data[k] * gq;
+                        }
+                    }
+                }
+                if (ramp_mask != 0ULL) wave_sync(); // the rows go back to the late half
+                if (tpos + 64 == blk_end) {
+                    // the block ends with this tile (a ramp that reaches the end of the call lands on its target exactly)
+                    if (g_ramp) g_cur = (blk_end == frames) ? g_tgt : g_run;
+                    if (fc < OALSFX_RV_FADE_SAMPLES) fc = min(fc + (blk_end - blk_start), OALSFX_RV_FADE_SAMPLES);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (MC ? 0 : 8); k += 2) {
+                    const v4f g = *reinterpret_cast<const v4f*>(utf + ut::GOUT + 2 * k);
+                    if (aud_out & (1u << (2 * k + 0))) o0 += data[k] * g.x;
+                    if (CH == 2 && (aud_out & (1u << (2 * k + 1)))) o1 += data[k] * g.y;
+                    if (aud_out & (1u << (2 * k + 2))) o0 += data[k + 1] * g.z;
+                    if (CH == 2 && (aud_out & (1u << (2 * k + 3)))) o1 += data[k + 1] * g.w;
+                }
             }
             if (MC || !act) {
                 // stored above / a lane past the end of a ragged call's last tile
@@ -1048,6 +1201,25 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             S.mod_index = static_cast<int>((static_cast<long long>(v_modidx) + frames) % v_modrange);
             S.offset = offset + frames;
             if (MD && mod_on) S.mod_filter = mod_f;
+        }
+        if (XF && xf_active) {
+            // the transition's own state: gains where the ramps left them, the fade count, the taps once they are faded in, the change
+            // marked as seen; and whether the instance ends the call settled and at rest
+            if (q_valid) {
+                if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
+                else S.early_cur_gain[q_line][q_chan] = g_cur;
+            }
+            const bool fade_over = fc >= OALSFX_RV_FADE_SAMPLES;
+            if (fc0 < OALSFX_RV_FADE_SAMPLES && fade_over && lane < 24) (&S.cur_early_tap[0])[lane] = static_cast<int32_t>(utu[kTapN + lane] >> 2);
+            if (lane == 0) {
+                S.fade_count = fc;
+                S.mod_range = v_modrange;
+                SS.seen_seq = SP.update_seq;
+            }
+            if (ctx.exact) {
+                const unsigned level = gains_rest_level(q_valid, g_cur, g_tgt);
+                if (lane == 0) ctx.exact[sidx] = fade_over ? level : 0u;
+            }
         }
         if (FP) {
             if (first && !filtered && lane < nch)
@@ -1085,11 +1257,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1738,7 +1910,8 @@ __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, 
     const int steady_groups = (steady_count + 3) >> 2;
     const int group = static_cast<int>(blockIdx.x);
     if (group < steady_groups) {
-        reverb_steady_group<CH, 4, false, true, true, true, RG, FP>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
+        // (whole tiles, not proven: the build that keeps instances in transition -- cross-fades, gain ramps -- in the grid)
+        reverb_steady_group<CH, 4, false, true, true, true, RG, FP, !RG && !FP>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
         return;
     }
     wfx::wave_block<CH>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
@@ -1771,7 +1944,7 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
         return "k_reverb_steady_coop<" #__VA_ARGS__ ">";                                                                         \
     } while (0)
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
-                                 bool proven, hipStream_t stream)
+                                 bool proven, bool in_transition, hipStream_t stream)
 {
     if (count <= 0) return nullptr;
     const dim3 grid((count + 3) / 4), block(256);
@@ -1802,6 +1975,12 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
     if (ragged) {
         if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, true, false);
         OALSFX_STEADY(2, 4, false, true, true, true, true, false);
+    }
+    if (in_transition) {
+        // some listed instance is folding in a property change (cross-fade, gain ramps): the variant of the most general build that
+        // keeps such instances in their workgroup instead of sending them down the general path
+        if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, false, false, true);
+        OALSFX_STEADY(2, 4, false, true, true, true, false, false, true);
     }
     if (c.channels == 1) {
         if (short_taps) OALSFX_STEADY(1, 4, false, true, true, true, false, false);

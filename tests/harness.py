@@ -218,3 +218,21 @@ class ShadowArmy:
         nan = np.isnan(y[self.instances]) & np.isnan(ref)
         bad = ((got != want) & ~nan).reshape(len(self.instances), -1).sum(axis=1)
         return [(self.instances[k], int(bad[k])) for k in np.nonzero(bad)[0]]
+
+
+def crossfade_followable(before, after):
+    """Mirror of the host's hint (hip/batch.cpp: crossfade_followable) on two `desc.ReverbParams`: can the cross-fading build of the
+    steady-state reverb kernel take an instance from one to the other (both tap sets ones its most general build accepts)?"""
+    sway = 0
+    if before.mod_depth != 0.0 or after.mod_depth != 0.0:
+        sway = 1 + int(max(abs(before.mod_depth), abs(after.mod_depth)))
+    for p in (before, after):
+        for j in range(4):
+            if (p.early_tap[j] < 0 or p.early_ap_off[j] < 16 or p.early_line_off[j] < 64 or p.late_tap[j] < after.late_feed_tap
+                    or p.late_ap_off[j] < 16 or p.late_line_off[j] < 64 + sway):
+                return False
+    return True
+
+
+def reverb_params(effect, fmt=desc.FMT_STEREO, rate=48000):
+    return lib.derive_slot(fmt, rate, lib.effect_normalized(effect)).u.reverb
