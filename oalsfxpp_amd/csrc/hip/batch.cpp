@@ -66,6 +66,8 @@ struct oalsfx_batch {
     std::vector<uint8_t> slot_class;              // [n*slots] kClass* bits of the slot's current parameters
     std::vector<size_t> settling;                 // reverb slots updated less than kSettleFrames ago
     std::vector<uint8_t> in_settling;             // [n*slots] membership flag of `settling`
+    std::vector<uint8_t> mod_ever;                // [n*slots] the slot's late line was modulated at some time since its state was created (the depth
+                                                  // smoother keeps moving long after the depth is set to 0)
     std::vector<uint8_t> xf_ok;                   // [n*slots] settling, and in a way the cross-fading build of the steady-state kernel follows
                                                   // (taps of both sets a tile away, state kept): listed with the believed-steady instances
     int n_close[OALSFX_MAX_SLOTS] = {};           // per slot: reverbs with a tap between one and two tiles ...
@@ -115,6 +117,8 @@ struct oalsfx_batch {
     int list_count[OALSFX_MAX_SLOTS][OALSFX_TYPE_COUNT] = {};
     int steady_offset[OALSFX_MAX_SLOTS] = {};     // start of the steady region: the proven instances, then the believed ones
     int fast_count[OALSFX_MAX_SLOTS] = {};        // proven steady (both reverb types)
+    int kind_count[OALSFX_MAX_SLOTS][3] = {};     // ... of which, in list order: every tap two tiles away; a tap of one to two tiles; shorter taps or a
+                                                  // modulated late line (the FP build each needs: plain, HY, ST)
     int rest_tiles[OALSFX_MAX_SLOTS] = {};        // ... whose output gains are at rest for blocks of that many tiles and longer (1 .. 4)
     int fast_first[OALSFX_MAX_SLOTS] = {};        // >= 0: the proven part of the list is the instance range fast_first, fast_first + 1, ...
     int slow_count[OALSFX_MAX_SLOTS] = {};        // believed steady (both reverb types)
@@ -448,8 +452,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     const size_t total = static_cast<size_t>(b->n) * b->slots;
     std::map<size_t, int> need; // size class -> slabs needed
     std::vector<size_t> restarted;
-    std::vector<int> up_params, up_state, up_source; // indices of the records to upload
-    std::vector<uint32_t> up_epoch;                  // new epochs of the instances in up_source
+    std::vector<int> up_params, up_state, up_source, up_touched; // indices of the records to upload
+    std::vector<uint32_t> up_epoch;                  // new epochs of the instances in up_touched
     bool any_type_change = false;
     if (!b->dirty_list.empty()) b->upload_gen += 1;
 
@@ -460,11 +464,12 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
 
     for (int i : b->dirty_list) {
         InstanceHost& h = b->inst[i];
-        bool updated = false;
+        bool updated = false, sends_moved = false;
         for (int s = 0; s < b->slots; ++s) {
             if (!h.slot_changed[s]) continue;
             h.slot_changed[s] = false;
             updated = true;
+            sends_moved |= h.slot_retyped[s]; // (the send to a slot depends on what the slot holds: nothing, or an effect)
             const size_t idx = static_cast<size_t>(i) * b->slots + s;
             oalsfx_slot_params& p = b->h_params[idx];
             // a settled reverb whose properties change without a change of type keeps its state and cross-fades: what the XF build follows
@@ -474,6 +479,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
             p.update_seq = ++b->seq[idx];
             up_params.push_back(static_cast<int>(idx));
             reclassify_slot(b, idx, s);
+            if (h.slot_retyped[s]) b->mod_ever[idx] = 0;
+            if (b->slot_class[idx] & kClassModulated) b->mod_ever[idx] = 1;
             b->xf_ok[idx] = was_settled && (b->slot_class[idx] & kClassSteady) != 0 && b->channels <= 2 && !(debug_flags() & 0x40000000) &&
                             crossfade_followable(before, p.u.reverb);
             b->lists_dirty = true; // (it leaves the proven part of its list, or the steady part altogether)
@@ -497,8 +504,12 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         if (h.source_changed) {
             h.source_changed = false;
             updated = true;
+            sends_moved = true;
         }
-        if (updated) {
+        // The reference recomputes a source's sends whenever one of its slots' properties changed (update_context_sources,
+        // src/oalsfxpp.cpp:3397-3412); their inputs -- send properties, which slots hold an effect -- did not move when only an effect's
+        // own properties did, and the result is the same record: derived and uploaded only when they did.
+        if (updated && sends_moved) {
             int types[OALSFX_MAX_SLOTS] = {};
             for (int s = 0; s < b->slots; ++s) types[s] = static_cast<int>(h.active[s].type_);
             oalsfx_source_params& sp = b->h_source[i];
@@ -512,6 +523,9 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
             derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, sp);
             b->n_filtered += static_cast<int>(has_filter(sp)) - static_cast<int>(before);
             up_source.push_back(i);
+        }
+        if (updated) {
+            up_touched.push_back(i);
             // whatever the device knew about this instance is out of date: its hot records (new epoch) and the proof that its reverbs
             // are steady (a send change alone leaves them steady, which the next read-back will confirm)
             up_epoch.push_back(++b->inst_epoch[i]);
@@ -572,42 +586,48 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     std::vector<int> lists;
     if (rebuild_lists) {
         lists.resize(total);
-        // ring-light types, then per reverb type: proven steady, believed steady, the others
-        constexpr int kFast = OALSFX_REVERB, kSlow = OALSFX_REVERB + 2, kGeneral = OALSFX_REVERB + 4, kBuckets = OALSFX_REVERB + 6;
+        // ring-light types, then the reverbs of both types: proven steady by kind (the FP build each needs: plain, close taps, short taps or
+        // modulated), believed steady or in a transition the XF build follows, the others
+        constexpr int kFast = OALSFX_REVERB, kSlow = OALSFX_REVERB + 3, kGeneral = OALSFX_REVERB + 4, kBuckets = OALSFX_REVERB + 5;
+        std::vector<uint8_t> bucket_of(b->n);
+        const bool force = (debug_flags() & 0x2000000) != 0; // test of the fault path only: every reverb counts as proven
         for (int s = 0; s < b->slots; ++s) {
+            // one pass over the slot's instances: bucket, type counts, and the shortest block (in tiles) that leaves the gains of every
+            // proven instance of the slot alone (calls whose last block is shorter do not take the FP builds)
             int count[kBuckets] = {};
-            auto bucket = [&](int i) {
+            b->list_count[s][OALSFX_REVERB] = b->list_count[s][OALSFX_EAX_REVERB] = 0;
+            b->rest_tiles[s] = 0;
+            for (int i = 0; i < b->n; ++i) {
                 const size_t idx = static_cast<size_t>(i) * b->slots + s;
                 const int t = b->h_params[idx].type;
-                if (t < OALSFX_REVERB) return t;
-                const bool force = (debug_flags() & 0x2000000) != 0; // test of the fault path only: every reverb counts as proven
-                const int cls = force ? kFast : !reverb_settled(b, idx) ? kGeneral : b->proven[idx] ? kFast : kSlow;
-                return cls + (t - OALSFX_REVERB);
-            };
-            for (int i = 0; i < b->n; ++i) count[bucket(i)] += 1;
+                int k = t;
+                if (t >= OALSFX_REVERB) {
+                    b->list_count[s][t] += 1;
+                    const uint8_t cls = b->slot_class[idx];
+                    if (!force && !reverb_settled(b, idx)) k = kGeneral;
+                    else if (!force && !b->proven[idx]) k = kSlow;
+                    else {
+                        k = kFast + (((cls & kClassShort) || b->mod_ever[idx]) ? 2 : (cls & kClassClose) ? 1 : 0);
+                        b->rest_tiles[s] = std::max<int>(b->rest_tiles[s], b->proven[idx]);
+                    }
+                }
+                bucket_of[i] = static_cast<uint8_t>(k);
+                count[k] += 1;
+            }
             int start[kBuckets];
             int off = s * b->n;
             for (int k = 0; k < kBuckets; ++k) { start[k] = off; off += count[k]; }
             for (int t = 0; t < OALSFX_REVERB; ++t) { b->list_offset[s][t] = start[t]; b->list_count[s][t] = count[t]; }
-            for (int t = 0; t < 2; ++t) {
-                b->list_offset[s][OALSFX_REVERB + t] = start[kFast]; // the reverb region as a whole (its types interleave by class)
-                b->list_count[s][OALSFX_REVERB + t] = count[kFast + t] + count[kSlow + t] + count[kGeneral + t];
-            }
-            // the shortest block (in tiles) that leaves the gains of every proven instance of the slot alone: calls whose last block
-            // is shorter go through the believing builds
-            b->rest_tiles[s] = 0;
-            for (int i = 0; i < b->n; ++i) {
-                const size_t idx = static_cast<size_t>(i) * b->slots + s;
-                if (b->h_params[idx].type >= OALSFX_REVERB && b->proven[idx] && reverb_settled(b, idx)) b->rest_tiles[s] = std::max<int>(b->rest_tiles[s], b->proven[idx]);
-            }
+            for (int t = 0; t < 2; ++t) b->list_offset[s][OALSFX_REVERB + t] = start[kFast]; // the reverb region as a whole (the two types interleave)
             b->steady_offset[s] = start[kFast];
-            b->fast_count[s] = count[kFast] + count[kFast + 1];
-            b->slow_count[s] = count[kSlow] + count[kSlow + 1];
+            for (int k = 0; k < 3; ++k) b->kind_count[s][k] = count[kFast + k];
+            b->fast_count[s] = count[kFast] + count[kFast + 1] + count[kFast + 2];
+            b->slow_count[s] = count[kSlow];
             b->general_offset[s] = start[kGeneral];
-            b->general_count[s] = count[kGeneral] + count[kGeneral + 1];
+            b->general_count[s] = count[kGeneral];
             int fill[kBuckets];
             for (int k = 0; k < kBuckets; ++k) fill[k] = start[k];
-            for (int i = 0; i < b->n; ++i) lists[fill[bucket(i)]++] = i;
+            for (int i = 0; i < b->n; ++i) lists[fill[bucket_of[i]]++] = i;
             // a proven part that is simply a range of instances needs no list on the device
             b->fast_first[s] = b->fast_count[s] > 0 ? lists[start[kFast]] : -1;
             for (int k = 1; k < b->fast_count[s]; ++k)
@@ -618,7 +638,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
 
     // ---- one packed upload: [indices | records] per array, the ring table, the lists ----
     auto padded = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
-    const size_t n_p = up_params.size(), n_s = up_state.size(), n_src = up_source.size();
+    const size_t n_p = up_params.size(), n_s = up_state.size(), n_src = up_source.size(), n_t = up_touched.size();
     size_t off = 0;
     const size_t o_pi = off; off += padded(n_p * sizeof(int));
     const size_t o_pr = off; off += padded(n_p * sizeof(oalsfx_slot_params));
@@ -626,7 +646,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     const size_t o_sr = off; off += padded(n_s * sizeof(oalsfx_slot_state));
     const size_t o_ci = off; off += padded(n_src * sizeof(int));
     const size_t o_cr = off; off += padded(n_src * sizeof(oalsfx_source_params));
-    const size_t o_ep = off; off += padded(n_src * sizeof(uint32_t));
+    const size_t o_ti = off; off += padded(n_t * sizeof(int));
+    const size_t o_ep = off; off += padded(n_t * sizeof(uint32_t));
     const size_t o_rt = off; off += rings_changed ? padded(total * sizeof(float*)) : 0;
     const size_t o_li = off; off += rebuild_lists ? padded(total * sizeof(int)) : 0;
     if (off > 0) {
@@ -638,7 +659,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         for (size_t k = 0; k < n_s; ++k) std::memcpy(st->host + o_sr + k * sizeof(oalsfx_slot_state), &b->h_state_init[up_state[k]], sizeof(oalsfx_slot_state));
         if (n_src) std::memcpy(st->host + o_ci, up_source.data(), n_src * sizeof(int));
         for (size_t k = 0; k < n_src; ++k) std::memcpy(st->host + o_cr + k * sizeof(oalsfx_source_params), &b->h_source[up_source[k]], sizeof(oalsfx_source_params));
-        if (n_src) std::memcpy(st->host + o_ep, up_epoch.data(), n_src * sizeof(uint32_t));
+        if (n_t) std::memcpy(st->host + o_ti, up_touched.data(), n_t * sizeof(int));
+        if (n_t) std::memcpy(st->host + o_ep, up_epoch.data(), n_t * sizeof(uint32_t));
         if (rings_changed) std::memcpy(st->host + o_rt, b->h_rings.data(), total * sizeof(float*));
         if (rebuild_lists) std::memcpy(st->host + o_li, lists.data(), total * sizeof(int));
         // Small uploads (parameter changes while streaming) are read by the kernels straight from the page-locked staging buffer: a
@@ -655,7 +677,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         jobs.scatter[0] = {reinterpret_cast<unsigned*>(b->d_params), words(o_pr), ints(o_pi), static_cast<int>(sizeof(oalsfx_slot_params) / 4), static_cast<int>(n_p)};
         jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_slot_state) / 4), static_cast<int>(n_s)};
         jobs.scatter[2] = {reinterpret_cast<unsigned*>(b->d_source), words(o_cr), ints(o_ci), static_cast<int>(sizeof(oalsfx_source_params) / 4), static_cast<int>(n_src)};
-        jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ci), 1, static_cast<int>(n_src)};
+        jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ti), 1, static_cast<int>(n_t)};
         jobs.copy[0] = {reinterpret_cast<unsigned*>(b->d_rings), words(o_rt), rings_changed ? total * (sizeof(float*) / 4) : 0, 0};
         jobs.copy[1] = {reinterpret_cast<unsigned*>(b->d_lists), words(o_li), rebuild_lists ? total : 0, 0};
         oalsfx_hip::launch_upload(jobs, b->stream);
@@ -689,7 +711,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // fused runs of reverb-free slots (one launch per slot; config 3: 118.4 against 107.5 us per step), 0x10000000 small parameter
 // uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step), 0x20000000 the
 // caller's stream takes a slot's first part instead of its general kernel, 0x40000000 no cross-fading build: reverbs whose properties
-// change go to the general kernel for 128 frames, as before round 3
+// change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
+// general path inside (experiment: what the fallback's scratch frame costs the grid)
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
 {
@@ -760,6 +783,39 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
         oalsfx_hip::launch_reverb_general(c, slot, list + lead, count - lead, flags, stream);
     }
+}
+
+// Mono / stereo, whole tiles: every steady reverb of the slot in one launch, each kind on the build it needs (the proven ones by their
+// taps: plain, HY or ST FP build; the believed ones and those in a transition the XF build follows on that build).  `proven_usable`:
+// the call's last block leaves the gains of the proven instances at rest; otherwise they go with the believed ones for this call (the
+// XF build ramps gains).
+void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, bool proven_usable, hipStream_t stream)
+{
+    int counts[4] = {0, 0, 0, b->slow_count[slot]};
+    if (proven_usable) for (int k = 0; k < 3; ++k) counts[k] = b->kind_count[slot][k];
+    else counts[3] += b->fast_count[slot];
+    // Every kind starts a new workgroup, and 4096 instances are exactly the 1024 workgroups the chip holds at once: one workgroup more
+    // runs behind all the others and takes the launch from 52 to 70 us (measured).  So a kind's last incomplete workgroup goes to the
+    // next populated kind instead, whose build is the more general one (plain < HY < ST; the XF build takes any steady instance): the
+    // boundary in the list moves down by up to three entries.
+    for (int k = 0; k < 3; ++k) {
+        int next = k + 1;
+        while (next < 4 && counts[next] == 0) ++next;
+        if (next == 4 || counts[k] == 0) continue;
+        const int carry = counts[k] & 3;
+        counts[k] -= carry;
+        counts[next] += carry;
+    }
+    KernelCtx c = ctx;
+    c.progress = nullptr;
+    // one proven kind alone: its list may be a plain range of instances
+    const bool one_kind = counts[3] == 0 && (counts[0] > 0) + (counts[1] > 0) + (counts[2] > 0) == 1;
+    c.list_first = one_kind ? b->fast_first[slot] : -1;
+    ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
+    const char* name = oalsfx_hip::launch_reverb_steady_kinds(c, slot, b->d_lists + b->steady_offset[slot], counts,
+                                                              flags | ((debug_flags() & 0xFF) << 8) | ((debug_flags() & 0x100) ? oalsfx_hip::kNoCuMajor : 0),
+                                                              (debug_flags() & 0x1000000) != 0, stream);
+    if (name) b->last_steady_kernel = name;
 }
 
 // The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of
@@ -965,11 +1021,12 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
             const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
             const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
-            const bool use_fast = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && gains_rest && b->slow_count[s] == 0 && !(debug_flags() & 0x200000);
-            const int fast = use_fast ? b->fast_count[s] : 0;
-            // parts: ring-light effects | proven-steady reverbs | believed-steady reverbs (all steady ones where the proven builds
-            // are not in play) | general reverbs
-            bool part_on[4] = {light > 0 && !mixed, fast > 0, steady - fast > 0, reverbs - steady > 0};
+            // (round 3: the proven instances no longer wait for the last believed one of their slot: one grid serves every kind,
+            // k_reverb_steady_kinds, each workgroup on the build its instances need)
+            const bool by_kind = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline;
+            const bool proven_usable = gains_rest && !(debug_flags() & 0x200000);
+            // parts: ring-light effects | (unused) | steady reverbs | general reverbs
+            bool part_on[4] = {light > 0 && !mixed, false, steady > 0, reverbs - steady > 0};
             int parts = 0;
             for (bool on : part_on) parts += on;
             const bool fork = parts > 1 && !(debug_flags() & 0x20000);
@@ -991,12 +1048,13 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 }
                 if (g == 0) {
                     launch_wave_group(b, ctx, s, flags, gs);
-                } else if (g == 1) {
-                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], fast, true, gs);
                 } else if (g == 2 && mixed) {
                     launch_mixed_part(b, ctx, s, flags, gs);
+                } else if (g == 2 && by_kind) {
+                    launch_reverb_kinds_part(b, ctx, s, flags, proven_usable, gs);
                 } else if (g == 2) {
-                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s] + fast, steady - fast, false, gs);
+                    // ragged calls, more than two channels, the timeline build: one launch of the believing builds for all of them
+                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], steady, false, gs);
                 } else {
                     launch_reverb_general_part(b, !use_steady, ctx, s, flags, gs);
                 }
@@ -1009,6 +1067,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_join[k], 0), "hipStreamWaitEvent")) return false;
         }
         done += n;
+    }
+    if ((frames % OALSFX_MAX_CHUNK) & 63) {
+        // a ragged chunk: a cross-fade in flight no longer stands at a tile boundary, which the XF build needs
+        for (size_t idx : b->settling)
+            if (b->xf_ok[idx]) { b->xf_ok[idx] = 0; b->lists_dirty = true; }
     }
     advance_settling(b, frames);
     if (b->exact_wanted && !b->exact_pending) {
@@ -1073,6 +1136,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->slot_class.assign(total, 0);
     b->in_settling.assign(total, 0);
     b->xf_ok.assign(total, 0);
+    b->mod_ever.assign(total, 0);
     b->proven.assign(total, 0);
     b->updated_gen.assign(total, 0);
     b->inst_epoch.assign(n_instances, 1); // a zero-filled hot record never carries a valid stamp

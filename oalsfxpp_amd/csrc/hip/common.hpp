@@ -90,6 +90,7 @@ struct WaveSegments {
 enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
+    kNoCuMajor = 32, // experiment (OALSFX_DEBUG_FLAGS 0x100): grids of several kinds in plain workgroup order
     kFiltered = 16, // the send-filter pre-pass (k_send_filters) ran: for the instances with a filter switched on, the planes at
                     // filtered_src / wet planes hold their sends' inputs and their filter histories are up to date
 };
@@ -108,6 +109,11 @@ constexpr int kWave = 64;
 // Returns the kernel symbol it launched (template arguments as rocprofv3 prints them), nullptr when the list was empty.
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated,
                                  bool short_taps, bool proven, bool in_transition, hipStream_t stream);
+// The steady reverbs of a slot listed by kind (mono / stereo, whole tiles): counts[0] proven, every tap two tiles away; [1] proven, a tap
+// of one to two tiles; [2] proven, shorter taps or a modulated late line; [3] believed steady or in a transition the XF build follows.
+// One kind alone runs its own lean kernel, several share one grid whose workgroups take the build of their kind.
+// no_fallback: the believed kind without the general path inside (the host predicts the kernel's test; a miss is counted in ctx.fault).
+const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments
@@ -140,6 +146,26 @@ void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStre
 #if defined(__HIPCC__)
 
 #define OALSFX_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+
+// A grid whose workgroups run different code (k_reverb_steady_kinds: one build per kind of instance; the ring-light grids: one body per
+// effect type) is ordered by kind, and consecutive workgroups land on consecutive CUs: workgroup g of a grid of 256-thread workgroups
+// that are all resident at once goes to CU slot g % 256 (measured, scripts/micro/placement.hip), so every CU would run every kind and
+// its instruction cache would hold none of them (measured: 4096 reverbs of four kinds 73 us per buffer against 57 with one kind).
+// This maps g to its position in CU-major order -- the workgroups that share a CU first, then the next CU -- so that a kind's
+// workgroups fill whole CUs.  Rounds of 1024 workgroups (four per CU); a bijection on [0, total) for any total.
+__device__ __forceinline__ int cu_major_position(int g, int total)
+{
+    const int base = g & ~1023;
+    const int n = min(total - base, 1024), l = g - base;
+    const int rounds = (n + 255) >> 8, rem = n - ((rounds - 1) << 8); // rem: how many CU slots have a workgroup in the last round
+    int c = l & 255;
+    const int r = l >> 8;
+#ifdef OALSFX_CU_ORDER_SE
+    // experiment: CU slots in shader-engine-major order (XCC, SE, CU): c = xcc + 8 * (se + 4 * cu)  ->  rank ((xcc * 4 + se) * 8 + cu)
+    if (n == 1024) c = (((c & 7) * 4 + ((c >> 3) & 3)) << 3) | (c >> 5);
+#endif
+    return base + (c < rem ? c * rounds + r : c * (rounds - 1) + rem + r);
+}
 
 __device__ __forceinline__ bool audible(float g) { return fabsf(g) > OALSFX_SILENCE_GAIN; }
 

@@ -287,7 +287,7 @@ struct SteadyShared {
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
 // kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, class SH>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
 {
@@ -1244,7 +1244,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
     } else
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
-    if (MC || ctx.progress != nullptr) {
+    if constexpr (NF) {
+        // NF: a build without the general path inside; the host lists only instances whose test it can predict from what it knows
+        // (DESIGN 4), and one that fails it anyway is counted like in an FP build
+        if (valid && lane == 0 && !go && ctx.fault) __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (MC || ctx.progress != nullptr) {
         // the general kernel follows on the same list: tell it how far this instance got
         if (valid && lane == 0) ctx.progress[sidx] = go ? frames : 0;
         if (valid && lane == 0 && !go && w < ctx.no_follow_up && ctx.fault) __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1257,11 +1261,53 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+}
+
+// One grid for a slot's steady reverbs of several kinds (mono / stereo, whole tiles).  The host orders the slot's list by kind and the
+// workgroups take the build of theirs: proven instances whose taps are all two tiles away (plain FP), proven ones with a tap of one to
+// two tiles (HY FP), proven ones with shorter taps or a modulated late line (the most general FP build), and the instances that are
+// believed steady or in a transition the XF build follows.  One property change, or one preset with a short tap, among thousands of
+// instances then costs its own workgroup the slower build and nobody else.  (NF: the last kind without the general path inside.)
+struct SteadyKinds {
+    int count[4]; // plain, close taps, short taps or modulated, believed / in transition: list entries, in this order; every kind starts a new workgroup
+    __host__ __device__ int groups(int k) const { return (count[k] + 3) >> 2; }
+};
+
+template <int CH, bool NF>
+__global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, int slot, const int* __restrict__ list, SteadyKinds kinds, int flags)
+{
+    union Shared {
+        SteadyShared<CH, 4, true, false, false> lean;    // plain and HY
+        SteadyShared<CH, 4, true, true, true> general;   // ST (includes MD)
+        SteadyShared<CH, 4, false, true, true> believed; // XF
+    };
+    __shared__ Shared sh;
+    // in CU-major order: the workgroups that share a CU run the same build (as far as the kinds' sizes allow)
+    int group = (flags & kNoCuMajor) ? static_cast<int>(blockIdx.x) : cu_major_position(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+    if (group < kinds.groups(0)) {
+        reverb_steady_group<CH, 4, false, false, false, false, false, true>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
+        return;
+    }
+    group -= kinds.groups(0);
+    list += kinds.count[0];
+    if (group < kinds.groups(1)) {
+        reverb_steady_group<CH, 4, false, true, false, false, false, true>(ctx, slot, list, kinds.count[1], flags, group, sh.lean);
+        return;
+    }
+    group -= kinds.groups(1);
+    list += kinds.count[1];
+    if (group < kinds.groups(2)) {
+        reverb_steady_group<CH, 4, false, true, true, true, false, true>(ctx, slot, list, kinds.count[2], flags, group, sh.general);
+        return;
+    }
+    group -= kinds.groups(2);
+    list += kinds.count[2];
+    reverb_steady_group<CH, 4, false, true, true, true, false, false, true, NF>(ctx, slot, list, kinds.count[3], flags, group, sh.believed);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
@@ -1995,6 +2041,36 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
     OALSFX_STEADY(2, 4, false, false, false, false, false, false);
 }
 #undef OALSFX_STEADY
+
+// The steady reverbs of a slot by kind (mono / stereo, whole tiles): counts[0] proven with every tap two tiles away, [1] proven with a
+// tap of one to two tiles, [2] proven with shorter taps or a modulated late line, [3] believed steady or in a transition the XF build
+// follows; `list` holds them in this order.  One kind alone takes its lean kernel, several share the grid of k_reverb_steady_kinds.
+const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, hipStream_t stream)
+{
+    const int total = counts[0] + counts[1] + counts[2] + counts[3];
+    if (total <= 0) return nullptr;
+    int populated = 0, only = 0;
+    for (int k = 0; k < 4; ++k)
+        if (counts[k] > 0) { ++populated; only = k; }
+    if (populated == 1 && !(only == 3 && no_fallback)) {
+        // (close_taps / modulated / short_taps select the FP build of the kind; the believed kind alone: the XF build with the general path inside)
+        return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream);
+    }
+    KernelCtx c = ctx;
+    c.list_first = -1; // (the kinds read their entries from the list)
+    SteadyKinds kinds{};
+    int groups = 0;
+    for (int k = 0; k < 4; ++k) { kinds.count[k] = counts[k]; groups += kinds.groups(k); }
+    const dim3 grid(groups), block(256);
+    if (c.channels == 1) {
+        if (no_fallback) { OALSFX_LAUNCH((k_reverb_steady_kinds<1, true>), grid, block, stream, c, slot, list, kinds, flags); return "k_reverb_steady_kinds<1, true>"; }
+        OALSFX_LAUNCH((k_reverb_steady_kinds<1, false>), grid, block, stream, c, slot, list, kinds, flags);
+        return "k_reverb_steady_kinds<1, false>";
+    }
+    if (no_fallback) { OALSFX_LAUNCH((k_reverb_steady_kinds<2, true>), grid, block, stream, c, slot, list, kinds, flags); return "k_reverb_steady_kinds<2, true>"; }
+    OALSFX_LAUNCH((k_reverb_steady_kinds<2, false>), grid, block, stream, c, slot, list, kinds, flags);
+    return "k_reverb_steady_kinds<2, false>";
+}
 
 // Everything else: cross-fades, modulation, gain ramps, taps closer than a tile, partial tiles, more than two channels.
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream)

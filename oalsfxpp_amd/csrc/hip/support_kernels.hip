@@ -299,15 +299,28 @@ void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, 
 // ---- the same for everything a parameter upload consists of, in one launch: up to four scatters and two plain copies.  The sources
 // may lie in page-locked host memory (small uploads are read from the staging buffer directly): one launch then costs one round of
 // reads over the link instead of one per array.
-__global__ __launch_bounds__(64) void k_upload(UploadJobs jobs)
+// Every load of a block is issued before its first store: the sources are read over the link (about 2 us a round trip), and a loop
+// of load-store pairs would make one round trip per iteration (round 2's kernel: 10 us for four changed reverbs; this one 3).
+__global__ __launch_bounds__(256) void k_upload(UploadJobs jobs)
 {
     int k = blockIdx.x;
+    const int t = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const ScatterJob& sj = jobs.scatter[j];
         if (k < sj.count) {
-            const size_t to = static_cast<size_t>(sj.indices[k]) * sj.record_dwords, from = static_cast<size_t>(k) * sj.record_dwords;
-            for (int i = threadIdx.x; i < sj.record_dwords; i += 64) sj.dst[to + i] = sj.packed[from + i];
+            const unsigned* __restrict__ from = sj.packed + static_cast<size_t>(k) * sj.record_dwords;
+            const int n = sj.record_dwords;
+            // records of up to 1024 dwords in one round (the descriptors are 142 to 380), longer ones in further rounds
+            for (int base = 0; base < n; base += 1024) {
+                unsigned v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = base + t + 256 * r < n ? from[base + t + 256 * r] : 0u;
+                const size_t to = static_cast<size_t>(sj.indices[k]) * n; // (read beside the record, not in front of it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (base + t + 256 * r < n) sj.dst[to + base + t + 256 * r] = v[r];
+            }
             return;
         }
         k -= sj.count;
@@ -316,12 +329,10 @@ __global__ __launch_bounds__(64) void k_upload(UploadJobs jobs)
     for (int j = 0; j < 2; ++j) {
         const CopyJob& cj = jobs.copy[j];
         if (k < cj.blocks) {
-            // 1024 dwords per block, 16 bytes per lane and round
-            const size_t lo = static_cast<size_t>(k) * 1024, hi = lo + 1024 < cj.dwords ? lo + 1024 : cj.dwords;
-            for (size_t i = lo + 4 * threadIdx.x; i < hi; i += 256) {
-                if (i + 4 <= hi) *reinterpret_cast<uint4*>(cj.dst + i) = *reinterpret_cast<const uint4*>(cj.src + i);
-                else for (size_t q = i; q < hi; ++q) cj.dst[q] = cj.src[q];
-            }
+            // 1024 dwords per block: 16 bytes per lane, one round
+            const size_t i = static_cast<size_t>(k) * 1024 + 4 * t;
+            if (i + 4 <= cj.dwords) *reinterpret_cast<uint4*>(cj.dst + i) = *reinterpret_cast<const uint4*>(cj.src + i);
+            else for (size_t q = i; q < cj.dwords; ++q) cj.dst[q] = cj.src[q];
             return;
         }
         k -= cj.blocks;
@@ -334,7 +345,7 @@ void launch_upload(UploadJobs jobs, hipStream_t stream)
     for (auto& sj : jobs.scatter) blocks += sj.count > 0 ? sj.count : (sj.count = 0);
     for (auto& cj : jobs.copy) { cj.blocks = static_cast<int>((cj.dwords + 1023) / 1024); blocks += cj.blocks; }
     if (blocks == 0) return;
-    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(64), 0, stream, jobs);
+    hipLaunchKernelGGL(k_upload, dim3(blocks), dim3(256), 0, stream, jobs);
 }
 
 // ---- buffer copies between page-locked host memory and device memory as a kernel (oalsfx_batch_mix_async): the copy engines of some

@@ -236,3 +236,14 @@ def crossfade_followable(before, after):
 
 def reverb_params(effect, fmt=desc.FMT_STEREO, rate=48000):
     return lib.derive_slot(fmt, rate, lib.effect_normalized(effect)).u.reverb
+
+
+def steady_build(symbol):
+    """What `Batch.last_reverb_kernel` says about the steady-state launch: {'kinds': the grid of several kinds, 'fp': a proven-steady build
+    (no steady-state test inside), 'xf': the build that follows property changes}.  Template arguments of k_reverb_steady_coop: channels,
+    wavefronts, TL, HY, MD, ST, RG, FP, XF."""
+    if symbol.startswith("k_reverb_steady_kinds"):
+        return {"kinds": True, "fp": False, "xf": False}
+    args = [a.strip() for a in symbol[symbol.index("<") + 1: symbol.rindex(">")].split(",")]
+    flag = lambda k: len(args) > k and args[k] == "true"
+    return {"kinds": False, "fp": flag(7), "xf": flag(8)}

@@ -8,7 +8,7 @@ the oracle."""
 import numpy as np
 import pytest
 
-from harness import OracleShadow, make_effect, preset_effect, same_bits
+from harness import OracleShadow, make_effect, preset_effect, same_bits, steady_build
 from oalsfxpp_amd import desc
 from oalsfxpp_amd.api import Batch
 from oracle import oracle as orc
@@ -63,13 +63,13 @@ def test_promotion_demotion_and_record_invalidation(fmt):
         f.mix(256)
         assert b.plan(0) == (0, n, 0, 0)                 # the device reported them settled, the host-pointer call waited: proven
         f.mix(256)                                        # records built from the descriptors
-        assert "true>" in b.last_reverb_kernel and b.last_reverb_kernel.endswith("false, true>")
+        assert steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
         f.mix(256); f.mix(64); f.mix(2048); f.mix(4096)  # record hits, every whole-tile call size, several chunks per call
         # a ragged call runs on the believing build and moves the delay-line positions: the records' stamps no longer match
         f.mix(100)
-        assert "false, true>" not in b.last_reverb_kernel
+        assert not steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
         f.mix(256); f.mix(256)
-        assert b.last_reverb_kernel.endswith("false, true>")
+        assert steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
         # a send change alone: off the proven list until the device confirms (it stays steady)
         b.set_send_props(-1, 0.7, 1.0, 1.0, first=2, count=1)
         b.set_send_props(0, 0.5, 1.0, 1.0, first=3, count=1)
@@ -119,7 +119,8 @@ def test_every_proven_build(fmt):
                 f.mix(frames)
             plan = f.b.plan(0)
             assert plan[1] > 0, f"{kind}: nothing was proven steady: {plan}"
-            assert f.b.last_reverb_kernel.endswith("true>"), (kind, f.b.last_reverb_kernel)
+            build = steady_build(f.b.last_reverb_kernel)   # a proven build alone, or the grid that gives every kind of instance its own
+            assert build["fp"] or build["kinds"], (kind, f.b.last_reverb_kernel)
             f.check_state()
         finally:
             f.close()
@@ -223,7 +224,7 @@ def test_output_gains_that_never_reach_their_target(fmt):
                     assert f.b.plan(0) == (0, len(setups), 0, 0)
                 f.mix(frames)
                 if k == 3 and fmt != desc.FMT_5POINT1:
-                    assert not f.b.last_reverb_kernel.endswith("true>"), f.b.last_reverb_kernel
+                    assert not steady_build(f.b.last_reverb_kernel)["fp"] and not steady_build(f.b.last_reverb_kernel)["kinds"], f.b.last_reverb_kernel
                 f.check_state()   # the current gains are state: a ramp that was skipped shows here even while the gain is inaudible
         finally:
             f.close()
