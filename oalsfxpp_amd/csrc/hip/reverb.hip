@@ -114,6 +114,38 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 {
     *reinterpret_cast<__attribute__((address_space(1))) float*>(slab + byte_off) = v;
 }
+// Non-temporal hints on the ring traffic of the steady-state kernel.  Bits of OALSFX_NT: 1 stores to the three long rings (main delay,
+// early line, late line: two thirds of the traffic, re-read tens of launches later at the earliest), 2 loads from them, 4 stores to the
+// two all-pass rings (96 MiB for 4096 instances, re-read within three launches), 8 loads from those, 16 the output frames, 32 the input
+// frames.  Measured in round 3 on the headline workload, each against the build without hints in one process (scripts/ab_nt.sh,
+// profiles/r03c_nontemporal/): 1: -4.1 %, 2: +-0, 1|2: -6.3 ... -6.8 % (47.1 -> 44.2 us), 1|4: -5.1 %, 1|2|4: +1.0 %, all four: +9.5 %,
+// 1|2|16: +3 % against 1|2, 1|2|32: -0.6 %.  What streams through for good is told so and leaves the caches to the all-pass rings,
+// which come back within a launch or three; hinting those too sends them to memory and back.  Default: 1|2.
+// (Also tried: the lanes of a wavefront's last, only begun 128-byte line without the hint, so that the next tile finds it cached: +2.1 %.
+// With the hints the cost of the unaligned taps -- every interior line fetched twice -- shows more: taps rounded to lines, an
+// ablation with wrong results, now gain 11 % where they gained 5 %.)
+#ifndef OALSFX_NT
+#define OALSFX_NT 3
+#endif
+template <int R> struct RingId { static constexpr int value = R; };
+constexpr bool long_ring(int r) { return r == OALSFX_RV_MAIN || r == OALSFX_RV_EARLY_LINE || r == OALSFX_RV_LATE_LINE; }
+// (the ring is a template argument: decided at run time, the two loads of one address are merged before the ring is known and the hint is lost)
+template <int R>
+__device__ __forceinline__ float ld_ring(const GlobalBytes* slab, unsigned byte_off)
+{
+    if constexpr (((OALSFX_NT & 2) && long_ring(R)) || ((OALSFX_NT & 8) && !long_ring(R)))
+        return __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(slab + byte_off));
+    else
+        return ld(slab, byte_off);
+}
+template <int R>
+__device__ __forceinline__ void st_ring(GlobalBytes* slab, unsigned byte_off, float v)
+{
+    if constexpr (((OALSFX_NT & 1) && long_ring(R)) || ((OALSFX_NT & 4) && !long_ring(R)))
+        __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) float*>(slab + byte_off));
+    else
+        st(slab, byte_off, v);
+}
 
 // delay_out_faded / delay_out_unfaded (reference src/oalsfxpp.cpp:7358-7399); pos4 = 4 * sample position
 __device__ __forceinline__ float tap(const GlobalBytes* slab, const Ring& r, int j, bool faded, unsigned pos4_0, unsigned pos4_1, float mu)
@@ -362,8 +394,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (!(flags & kFiltered)) {
             const float* raw = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
             if (CH == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(raw + static_cast<size_t>(lane) * 2);
-                early_in0 = v.x; early_in1 = v.y;
+                if (OALSFX_NT & 32) {
+                    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(raw + static_cast<size_t>(lane) * 2));
+                    early_in0 = v.x; early_in1 = v.y;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(raw + static_cast<size_t>(lane) * 2);
+                    early_in0 = v.x; early_in1 = v.y;
+                }
             } else {
                 early_in0 = raw[lane];
             }
@@ -594,15 +631,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     float n_wv[MC ? 8 : 1] = {};
     // XF: which tap table is current in a tile: the one being faded in once the fade is through
     auto tapbase = [&](int tile) -> int { return (XF && fc0 < OALSFX_RV_FADE_SAMPLES && fc0 + (tile << 6) >= OALSFX_RV_FADE_SAMPLES) ? kTapN : static_cast<int>(ut::TAP4); };
-    auto load4 = [&](unsigned t4x, int group, int r, int base = ut::TAP4) -> v4f {
+    auto load4 = [&](unsigned t4x, int group, auto ring, int base = ut::TAP4) -> v4f {
+        constexpr int r = decltype(ring)::value;
         const v4u d = *reinterpret_cast<const v4u*>(utu + base + 4 * group);
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
         const unsigned bm = utu[ut::BMASK + r];
         v4f v;
-        v.x = ld(slab_b, ((t4x - d.x) & bm) | lo.x);
-        v.y = ld(slab_b, ((t4x - d.y) & bm) | lo.y);
-        v.z = ld(slab_b, ((t4x - d.z) & bm) | lo.z);
-        v.w = ld(slab_b, ((t4x - d.w) & bm) | lo.w);
+        v.x = ld_ring<r>(slab_b, ((t4x - d.x) & bm) | lo.x);
+        v.y = ld_ring<r>(slab_b, ((t4x - d.y) & bm) | lo.y);
+        v.z = ld_ring<r>(slab_b, ((t4x - d.z) & bm) | lo.z);
+        v.w = ld_ring<r>(slab_b, ((t4x - d.w) & bm) | lo.w);
         return v;
     };
     // modulated late line (reference calc_modulation_delays, src/oalsfxpp.cpp:7443-7470): delay of this lane's sample in
@@ -644,8 +682,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     if (c < nch) n_wv[MC ? c : 0] = wsrc[static_cast<size_t>(px) * nch + c];
             }
         } else if (CH == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
-            n_in0 = v.x; n_in1 = v.y;
+            if (OALSFX_NT & 32) {
+                const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(src + static_cast<size_t>(px) * 2));
+                n_in0 = v.x; n_in1 = v.y;
+            } else {
+                const float2 v = *reinterpret_cast<const float2*>(src + static_cast<size_t>(px) * 2);
+                n_in0 = v.x; n_in1 = v.y;
+            }
             if (filtered) {
                 const float2 u = *reinterpret_cast<const float2*>(wsrc + static_cast<size_t>(px) * 2);
                 n_w0 = u.x; n_w1 = u.y;
@@ -657,21 +700,22 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     };
     // the ring requests of a tile in three parts (S1, S3, S5 of the iteration before its late half)
     auto issue_taps_a = [&](unsigned t4x, int base) {
-        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, OALSFX_RV_MAIN, base);
-        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, OALSFX_RV_EARLY_AP, base);
+        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, RingId<OALSFX_RV_MAIN>{}, base);
+        if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, RingId<OALSFX_RV_EARLY_AP>{}, base);
     };
     auto issue_taps_b = [&](unsigned t4x, int base) {
-        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, OALSFX_RV_EARLY_LINE, base);
-        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, OALSFX_RV_MAIN, base);
-        if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, OALSFX_RV_LATE_LINE, base);
+        if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, RingId<OALSFX_RV_EARLY_LINE>{}, base);
+        if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, RingId<OALSFX_RV_MAIN>{}, base);
+        if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, RingId<OALSFX_RV_LATE_LINE>{}, base);
     };
     auto issue_taps_c = [&](unsigned t4x, int base) {
-        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, OALSFX_RV_LATE_AP, base);
+        if (!HY || !(late_mask & 16u)) n_la = load4(t4x, 4, RingId<OALSFX_RV_LATE_AP>{}, base);
     };
-    auto store4 = [&](unsigned p4, int r, float v0, float v1, float v2, float v3) {
+    auto store4 = [&](unsigned p4, auto ring, float v0, float v1, float v2, float v3) {
+        constexpr int r = decltype(ring)::value;
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
         const unsigned wp = p4 & utu[ut::BMASK + r];
-        st(slab_b, wp | lo.x, v0); st(slab_b, wp | lo.y, v1); st(slab_b, wp | lo.z, v2); st(slab_b, wp | lo.w, v3);
+        st_ring<r>(slab_b, wp | lo.x, v0); st_ring<r>(slab_b, wp | lo.y, v1); st_ring<r>(slab_b, wp | lo.z, v2); st_ring<r>(slab_b, wp | lo.w, v3);
     };
     // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 4 * NW
     const int cw = (lane >> 2) & (NW - 1), cc = lane & 3;
@@ -750,20 +794,20 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (HY && has_b) {
                 // groups with a tap closer than two tiles: requested now, after the previous tile's stores
                 const int base = tapbase(tb);
-                if (late_mask & 1u) p_e = load4(t4, 0, OALSFX_RV_MAIN, base);
-                if (late_mask & 2u) p_a = load4(t4, 1, OALSFX_RV_EARLY_AP, base);
-                if (late_mask & 4u) p_el = load4(t4, 2, OALSFX_RV_EARLY_LINE, base);
-                if (late_mask & 8u) p_lt = load4(t4, 3, OALSFX_RV_MAIN, base);
-                if (late_mask & 16u) p_la = load4(t4, 4, OALSFX_RV_LATE_AP, base);
-                if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, OALSFX_RV_LATE_LINE, base);
+                if (late_mask & 1u) p_e = load4(t4, 0, RingId<OALSFX_RV_MAIN>{}, base);
+                if (late_mask & 2u) p_a = load4(t4, 1, RingId<OALSFX_RV_EARLY_AP>{}, base);
+                if (late_mask & 4u) p_el = load4(t4, 2, RingId<OALSFX_RV_EARLY_LINE>{}, base);
+                if (late_mask & 8u) p_lt = load4(t4, 3, RingId<OALSFX_RV_MAIN>{}, base);
+                if (late_mask & 16u) p_la = load4(t4, 4, RingId<OALSFX_RV_LATE_AP>{}, base);
+                if (late_mask & 32u) p_ll = load4(MD ? t4 - 4u * static_cast<unsigned>(md_cur) : t4, 5, RingId<OALSFX_RV_LATE_LINE>{}, base);
             }
             if (XF && xf_faded) {
                 // a cross-fading tile (reference delay_out_faded, src/oalsfxpp.cpp:7378-7399): the taps being faded in are requested here,
                 // behind the previous tile's stores, and mixed with the current ones sample by sample: the two lines at once (their taps
                 // are a tile away), the others where they are used, behind the hand-over inside the tile that either set may need
-                q_e = load4(t4, 0, OALSFX_RV_MAIN, kTapN); q_a = load4(t4, 1, OALSFX_RV_EARLY_AP, kTapN);
-                q_lt = load4(t4, 3, OALSFX_RV_MAIN, kTapN);
-                const v4f q_el = load4(t4, 2, OALSFX_RV_EARLY_LINE, kTapN), q_ll = load4(t4 - 4u * static_cast<unsigned>(md_cur), 5, OALSFX_RV_LATE_LINE, kTapN);
+                q_e = load4(t4, 0, RingId<OALSFX_RV_MAIN>{}, kTapN); q_a = load4(t4, 1, RingId<OALSFX_RV_EARLY_AP>{}, kTapN);
+                q_lt = load4(t4, 3, RingId<OALSFX_RV_MAIN>{}, kTapN);
+                const v4f q_el = load4(t4, 2, RingId<OALSFX_RV_EARLY_LINE>{}, kTapN), q_ll = load4(t4 - 4u * static_cast<unsigned>(md_cur), 5, RingId<OALSFX_RV_LATE_LINE>{}, kTapN);
                 mix4(p_el, q_el); mix4(p_ll, q_ll);
             }
             // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts (top and end of S1, S3): a wavefront
@@ -775,7 +819,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         v2f e01 = {0, 0}, e23 = {0, 0};
         float dg = 0.0F, ac = 0.0F, sx = 0.0F, sy = 0.0F;
         if (go && has_b) {
-            if (act) store4(t4, OALSFX_RV_MAIN, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
+            if (act) store4(t4, RingId<OALSFX_RV_MAIN>{}, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
             wave_sync();
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
@@ -841,15 +885,15 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             v2f g23 = f23 + (ac * v23);
             scatter2(g01, g23, sx, sy);
             if (act) {
-                store4(t4, OALSFX_RV_EARLY_AP, g01.x, g01.y, g23.x, g23.y);
-                store4(t4, OALSFX_RV_EARLY_LINE, v23.y, v23.x, v01.y, v01.x);
+                store4(t4, RingId<OALSFX_RV_EARLY_AP>{}, g01.x, g01.y, g23.x, g23.y);
+                store4(t4, RingId<OALSFX_RV_EARLY_LINE>{}, v23.y, v23.x, v01.y, v01.x);
             }
             e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
             e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
             {
                 v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
                 scatter2(r01, r23, sx, sy);
-                if (act) store4(t4 - utu[ut::FEED4], OALSFX_RV_MAIN, r01.x, r01.y, r23.x, r23.y);
+                if (act) store4(t4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, r01.x, r01.y, r23.x, r23.y);
                 if (ST && (short_mask & 8u)) {
                     // late taps closer than a tile to the late feed read what an earlier lane just fed
                     strow(4)[4 + lane] = r01.x; strow(5)[4 + lane] = r01.y; strow(6)[4 + lane] = r23.x; strow(7)[4 + lane] = r23.y;
@@ -1051,7 +1095,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             const v2f i23 = {rowL(1, 2)[4 + lane], rowL(1, 3)[4 + lane]};
             // XF, a cross-fading tile: the late all-pass taps being faded in are requested here (nothing of this tile has touched that ring yet)
             v4f q_la = {0, 0, 0, 0};
-            if (XF && xf_faded) q_la = load4(t4, 4, OALSFX_RV_LATE_AP, kTapN);
+            if (XF && xf_faded) q_la = load4(t4, 4, RingId<OALSFX_RV_LATE_AP>{}, kTapN);
             if (ST && (short_mask & 16u)) {
                 // late all-pass offsets shorter than the tile, as for the early all-pass
                 const v4u d = *reinterpret_cast<const v4u*>(utu + (XF ? tb_base : static_cast<int>(ut::TAP4)) + 16);
@@ -1088,10 +1132,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
             v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
             scatter2(q01, q23, sx, sy);
-            if (act) store4(t4, OALSFX_RV_LATE_AP, q01.x, q01.y, q23.x, q23.y);
+            if (act) store4(t4, RingId<OALSFX_RV_LATE_AP>{}, q01.x, q01.y, q23.x, q23.y);
             v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
             scatter2(r01, r23, sx, sy);
-            if (act) store4(t4, OALSFX_RV_LATE_LINE, r01.x, r01.y, r23.x, r23.y);
+            if (act) store4(t4, RingId<OALSFX_RV_LATE_LINE>{}, r01.x, r01.y, r23.x, r23.y);
             const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
             if (MC) {
                 // early lines 0..3 then late lines 0..3, each into every audible channel (reference src/oalsfxpp.cpp:6142-6166)
@@ -1170,8 +1214,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (MC || !act) {
                 // stored above / a lane past the end of a ragged call's last tile
             } else if (last) {
-                if (CH == 2) *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos_b) * 2) = make_float2(o0, o1);
-                else dst[pos_b] = o0;
+                if (CH == 2) {
+                    if (OALSFX_NT & 16) __builtin_nontemporal_store(v2f{o0, o1}, reinterpret_cast<v2f*>(dst + static_cast<size_t>(pos_b) * 2));
+                    else *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos_b) * 2) = make_float2(o0, o1);
+                } else dst[pos_b] = o0;
             } else {
                 mixbuf[pos_b] = o0;
                 if (CH == 2) mixbuf[OALSFX_MAX_CHUNK + pos_b] = o1;
