@@ -33,6 +33,9 @@ CHANNELS = 2
 BYTES_PER_FRAME = 208          # 16 B I/O + 24 fp32 delay-line reads + 24 fp32 delay-line writes
 TIMED_EVERY = int(os.environ.get("OALSFX_TIMED_EVERY", "8"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+VALU_SIMDS = 1024              # 256 CUs x 4 SIMDs
+VALU_CLOCK_GHZ = 2.4
+VALU_CYCLES_PER_WAVE_INSTRUCTION = 4   # a wave64 VALU instruction holds its 16-lane SIMD for four cycles
 METRIC = "Msamples/sec EAX reverb, 256-frame buffers, batch=4096; % HBM roofline"
 METRICS = {
     "config3": "Msamples/sec 4-slot chain (chorus, flanger, echo, EAX reverb), 256-frame buffers, batch=4096; % HBM roofline",
@@ -381,6 +384,23 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": None, "kernel": "all effect kernels of a step (algorithmic bytes of the step / step time)",
                     "kernel_us": round(step_s * 1e6, 2), "launches_timed": args.steps, "algorithmic_bytes_per_launch": bytes_per_step}
+    issue_file = os.path.join(ROOT, "profiles", "valu_issue.json")
+    if workload in ("config3", "config4") and os.path.exists(issue_file) and n == {"config3": 4096, "config4": 8192}[workload]:
+        # These steps are not bound by bytes (16 to 32 B per frame for most of their effect types) but by instruction issue: serial filter
+        # recurrences on a few lanes still hold a SIMD for four cycles per wave instruction.  The bound that fits: the share of the chip's
+        # VALU issue slots the step uses, from the committed counter pass (wave-level VALU instructions per step) and this run's step time.
+        with open(issue_file) as f:
+            vi = json.load(f).get(workload)
+        if vi:
+            insts = vi["valu_wave_instructions_per_step"]
+            peak = VALU_SIMDS * VALU_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTRUCTION   # G wave-instructions per second
+            achieved = insts / (elapsed / args.steps) / 1e9
+            roofline = {"bound": "valu-issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                        "frac": round(achieved / peak, 4), "traffic": None,
+                        "kernel": "all effect kernels of a step (VALU wave instructions of the step, profiles/valu_issue.json / step time)",
+                        "kernel_us": roofline["kernel_us"], "launches_timed": args.steps, "valu_wave_instructions_per_step": insts,
+                        "peak_note": f"{VALU_SIMDS} SIMDs x {VALU_CLOCK_GHZ} GHz / {VALU_CYCLES_PER_WAVE_INSTRUCTION} cycles per wave64 instruction",
+                        "hbm": {k: roofline[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch")}}
     pc, pk, pbest, pworst = batch.placement()
     roofline["delay_line_placement"] = {"chunks": pc, "candidates_probed": pk, "probe_us_kept": round(pbest, 2), "probe_us_slowest_seen": round(pworst, 2),
                                         "note": "the runtime keeps the fastest of a few candidate allocations for the delay lines (traffic-only probe; DESIGN 2)"}
