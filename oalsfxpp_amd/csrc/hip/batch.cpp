@@ -250,9 +250,9 @@ uint8_t classify_slot(const oalsfx_slot_params& sp)
     const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
     int lo = 1 << 30;
     for (int j = 0; j < 4; ++j) {
-        // what the most general build of the steady-state kernel accepts: early / late taps of any length, all-pass
-        // offsets from a quarter tile, line offsets from one tile
-        if (p.early_tap[j] < 0 || p.early_ap_off[j] < 16 || p.early_line_off[j] < 64 || p.late_ap_off[j] < 16 ||
+        // what the most general build of the steady-state kernel accepts: early / late taps and early-line offsets of any length,
+        // all-pass offsets from four samples, late-line offsets from one tile
+        if (p.early_tap[j] < 0 || p.early_ap_off[j] < 4 || p.early_line_off[j] < 0 || p.late_ap_off[j] < 4 ||
             p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap)
             cls &= static_cast<uint8_t>(~kClassSteady);
         lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
@@ -280,8 +280,8 @@ bool crossfade_followable(const oalsfx_reverb_params& from, const oalsfx_reverb_
     const int sway = (from.mod_depth != 0.0F || to.mod_depth != 0.0F) ? 1 + static_cast<int>(std::max(std::abs(from.mod_depth), std::abs(to.mod_depth))) : 0;
     for (const oalsfx_reverb_params* p : {&from, &to})
         for (int j = 0; j < 4; ++j)
-            if (p->early_tap[j] < 0 || p->early_ap_off[j] < 16 || p->early_line_off[j] < 64 || p->late_tap[j] < to.late_feed_tap ||
-                p->late_ap_off[j] < 16 || p->late_line_off[j] < 64 + sway)
+            if (p->early_tap[j] < 0 || p->early_ap_off[j] < 4 || p->early_line_off[j] < 0 || p->late_tap[j] < to.late_feed_tap ||
+                p->late_ap_off[j] < 4 || p->late_line_off[j] < 64 + sway)
                 return false;
     return true;
 }

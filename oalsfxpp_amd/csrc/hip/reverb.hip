@@ -273,10 +273,10 @@ __device__ __forceinline__ void lds_barrier()
 // MD (implies HY): instances with a modulated late line are accepted: the depth smoother (a serial lerp chain) runs on
 // lane 0 of each wavefront one tile ahead, the per-sample delays shift the late-line requests.
 // ST (implies HY and MD): taps shorter than a tile where the data they read is produced inside the tile without a loop
-// through the reverb core, or where a few extra evaluations settle it: early taps and late taps of any length (their
-// sources, the filtered input and the late feed of an earlier lane, are handed over through LDS rows), and vector
-// all-pass offsets of 16..63 samples (the all-pass outputs of the first lanes are evaluated ahead, up to three times,
-// and handed over).
+// through the reverb core, or where a few extra evaluations settle it: early taps, late taps and early-line offsets of any
+// length (their sources -- the filtered input, the late feed, the reversed all-pass output of an earlier lane -- are handed
+// over through LDS rows), and vector all-pass offsets of 4..63 samples (the all-pass outputs of the first lanes are
+// evaluated ahead, 63 / offset times, and handed over; offsets under 16 only occur below 16 kHz).
 // CH == 8: the multichannel build (quad .. 7.1, channel count at run time): send and pan gains live in a second table,
 // the dry mix and the panning loop over the channels, and an instance that is not steady is not taken inside the kernel
 // (its LDS would have to be sized for the general path's 64 gain ramps) but left, through ctx.progress, to the general
@@ -508,8 +508,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // a modulated late line reads up to |depth| samples closer (the smoother moves monotonically towards the depth)
         if (MD && (lane >> 2) == 5) feed4 = 4u * (1u + static_cast<unsigned>(fmaxf(fabsf(P.mod_depth), fabsf(v_modf))));
         const int grp = lane >> 2;
-        // shortest distance accepted per group: early / late taps any, all-pass offsets a quarter tile (ST build only)
-        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 64u : 256u;
+        // shortest distance accepted per group (ST build only)
+        // (ST: early and late taps and the early line of any length, all-pass offsets from four samples -- up to fifteen evaluations ahead
+        // per tile --, the late line a whole tile: its loop runs through the T60 chain phases)
+        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 2 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 16u : 256u;
         if (__ballot(tp >= shortest + feed4 && tpn >= shortest + feed4) != ~0ULL) go = false;
         if (ST) {
             const unsigned long long in_tile = __ballot(lane < 24 && (tp < 256u + feed4 || tpn < 256u + feed4));
@@ -780,7 +782,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // XF: is the late half's tile one in which the taps are cross-faded?  mu: how far, per sample; q_*: the taps being faded in
         const bool xf_faded = XF && xf_active && has_b && fc0 + (tb << 6) < OALSFX_RV_FADE_SAMPLES;
         const float mu = static_cast<float>(fc0 + pos_b) * (1.0F / OALSFX_RV_FADE_SAMPLES);
-        v4f q_e = {0, 0, 0, 0}, q_a = q_e, q_lt = q_e;
+        v4f q_e = {0, 0, 0, 0}, q_a = q_e, q_lt = q_e, q_el = q_e;
         auto mix4 = [&](v4f& a, const v4f& b) {
             a.x = lerpf(a.x, b.x, mu); a.y = lerpf(a.y, b.y, mu); a.z = lerpf(a.z, b.z, mu); a.w = lerpf(a.w, b.w, mu);
         };
@@ -803,12 +805,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             }
             if (XF && xf_faded) {
                 // a cross-fading tile (reference delay_out_faded, src/oalsfxpp.cpp:7378-7399): the taps being faded in are requested here,
-                // behind the previous tile's stores, and mixed with the current ones sample by sample: the two lines at once (their taps
+                // behind the previous tile's stores, and mixed with the current ones sample by sample: the late line at once (its taps
                 // are a tile away), the others where they are used, behind the hand-over inside the tile that either set may need
                 q_e = load4(t4, 0, RingId<OALSFX_RV_MAIN>{}, kTapN); q_a = load4(t4, 1, RingId<OALSFX_RV_EARLY_AP>{}, kTapN);
                 q_lt = load4(t4, 3, RingId<OALSFX_RV_MAIN>{}, kTapN);
-                const v4f q_el = load4(t4, 2, RingId<OALSFX_RV_EARLY_LINE>{}, kTapN), q_ll = load4(t4 - 4u * static_cast<unsigned>(md_cur), 5, RingId<OALSFX_RV_LATE_LINE>{}, kTapN);
-                mix4(p_el, q_el); mix4(p_ll, q_ll);
+                q_el = load4(t4, 2, RingId<OALSFX_RV_EARLY_LINE>{}, kTapN);
+                const v4f q_ll = load4(t4 - 4u * static_cast<unsigned>(md_cur), 5, RingId<OALSFX_RV_LATE_LINE>{}, kTapN);
+                mix4(p_ll, q_ll);
             }
             // the ring requests of tile ta (its late half runs in the next iteration) go out in three parts (top and end of S1, S3): a wavefront
             // that issues all 24 in one go sits in the issue queue while its siblings and its own arithmetic wait
@@ -888,6 +891,25 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 store4(t4, RingId<OALSFX_RV_EARLY_AP>{}, g01.x, g01.y, g23.x, g23.y);
                 store4(t4, RingId<OALSFX_RV_EARLY_LINE>{}, v23.y, v23.x, v01.y, v01.x);
             }
+            if (ST && (short_mask & 4u)) {
+                // early-line offsets shorter than the tile (sampling rates below 16 kHz) read what an earlier lane just wrote to the line: the
+                // reversed all-pass output, which does not depend on the line (no loop to settle: one hand-over; an offset of zero reads the
+                // lane's own, as the reference's just-written slot does)
+                strow(0)[4 + lane] = v23.y; strow(1)[4 + lane] = v23.x; strow(2)[4 + lane] = v01.y; strow(3)[4 + lane] = v01.x;
+                wave_sync();
+                auto hand_over = [&](v4f& v, int base) {
+                    const v4u d = *reinterpret_cast<const v4u*>(utu + base + 8);
+                    const int e0 = static_cast<int>(d.x >> 2), e1 = static_cast<int>(d.y >> 2), e2 = static_cast<int>(d.z >> 2), e3 = static_cast<int>(d.w >> 2);
+                    if (lane >= e0) v.x = strow(0)[4 + lane - e0];
+                    if (lane >= e1) v.y = strow(1)[4 + lane - e1];
+                    if (lane >= e2) v.z = strow(2)[4 + lane - e2];
+                    if (lane >= e3) v.w = strow(3)[4 + lane - e3];
+                };
+                hand_over(p_el, XF ? tb_base : static_cast<int>(ut::TAP4));
+                if (XF && xf_faded) hand_over(q_el, kTapN);
+                wave_sync();
+            }
+            if (XF && xf_faded) mix4(p_el, q_el);
             e01 = v01 + (v2f{p_el.x, p_el.y} * v2f{elc.x, elc.y});
             e23 = v23 + (v2f{p_el.z, p_el.w} * v2f{elc.z, elc.w});
             {

@@ -228,8 +228,8 @@ def crossfade_followable(before, after):
         sway = 1 + int(max(abs(before.mod_depth), abs(after.mod_depth)))
     for p in (before, after):
         for j in range(4):
-            if (p.early_tap[j] < 0 or p.early_ap_off[j] < 16 or p.early_line_off[j] < 64 or p.late_tap[j] < after.late_feed_tap
-                    or p.late_ap_off[j] < 16 or p.late_line_off[j] < 64 + sway):
+            if (p.early_tap[j] < 0 or p.early_ap_off[j] < 4 or p.early_line_off[j] < 0 or p.late_tap[j] < after.late_feed_tap
+                    or p.late_ap_off[j] < 4 or p.late_line_off[j] < 64 + sway):
                 return False
     return True
 
