@@ -75,6 +75,12 @@ struct oalsfx_batch {
     bool modulated[OALSFX_MAX_SLOTS] = {};        // some reverb of the slot has, or had, a modulated late line (sticky: the depth
                                                   // smoother keeps moving long after the depth is set to 0)
     int n_filtered = 0;                           // instances with a send filter switched on
+    std::vector<uint8_t> inst_filtered;           // [n] ... which
+    std::vector<int> h_lists;                     // host copy of d_lists as last built
+    uint32_t lists_version = 0;
+    // how many filtered instances the SF builds take care of themselves (launch_reverb_kinds_part), cached per list version and boundary
+    uint32_t inside_version = ~0u;
+    int inside_end = -1, inside_filtered = 0;
     // What the host *knows* about the reverb slots (as opposed to believes): a slot is proven steady once the device has reported it
     // settled and at rest (d_exact, read back without ever waiting for the stream) and nothing has been uploaded for its instance since.
     std::vector<uint8_t> proven;                  // [n*slots] 0, or from how many tiles a block on the slot's output gains are at rest (1 .. 4)
@@ -522,6 +528,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
             const bool before = has_filter(sp);
             derive_source(b->dev, b->slots, h.direct_props, h.aux_props, types, sp);
             b->n_filtered += static_cast<int>(has_filter(sp)) - static_cast<int>(before);
+            b->inst_filtered[i] = has_filter(sp) ? 1 : 0;
+            b->inside_version = ~0u;
             up_source.push_back(i);
         }
         if (updated) {
@@ -634,6 +642,8 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
                 if (lists[start[kFast] + k] != b->fast_first[s] + k) { b->fast_first[s] = -1; break; }
         }
         b->lists_dirty = false;
+        b->h_lists = lists;
+        b->lists_version += 1;
     }
 
     // ---- one packed upload: [indices | records] per array, the ring table, the lists ----
@@ -712,7 +722,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // uploads through the copy engine like bulk ones (update storm, 4 changes per buffer: 216 against 170 us per step), 0x20000000 the
 // caller's stream takes a slot's first part instead of its general kernel, 0x40000000 no cross-fading build: reverbs whose properties
 // change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
-// general path inside (experiment: what the fallback's scratch frame costs the grid)
+// general path inside (experiment: what the fallback's scratch frame costs the grid), 0x200 no send filters inside the steady-state
+// builds (the pre-pass kernel for every filtered instance, as before round 3)
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
 {
@@ -789,9 +800,10 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
 // taps: plain, HY or ST FP build; the believed ones and those in a transition the XF build follows on that build).  `proven_usable`:
 // the call's last block leaves the gains of the proven instances at rest; otherwise they go with the believed ones for this call (the
 // XF build ramps gains).
-void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, bool proven_usable, hipStream_t stream)
+void steady_kind_counts(const oalsfx_batch* b, int slot, bool proven_usable, int counts[4])
 {
-    int counts[4] = {0, 0, 0, b->slow_count[slot]};
+    counts[0] = counts[1] = counts[2] = 0;
+    counts[3] = b->slow_count[slot];
     if (proven_usable) for (int k = 0; k < 3; ++k) counts[k] = b->kind_count[slot][k];
     else counts[3] += b->fast_count[slot];
     // Every kind starts a new workgroup, and 4096 instances are exactly the 1024 workgroups the chip holds at once: one workgroup more
@@ -806,6 +818,29 @@ void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, i
         counts[k] -= carry;
         counts[next] += carry;
     }
+}
+
+// Single-slot batches whose steady reverbs go by kind: the first two kinds' builds filter their own sends (SF, reverb.hip), the pre-pass
+// covers the rest of the list.  Returns how many filtered instances those two kinds hold (0: no SF builds this call).
+int filters_inside_count(oalsfx_batch* b, int slot, const int counts[4])
+{
+    if (b->slots != 1 || b->channels > 2 || b->n_filtered == 0 || counts[0] + counts[1] == 0 || (debug_flags() & 0x200)) return 0;
+    const int end = counts[0] + counts[1];
+    if (b->inside_version != b->lists_version || b->inside_end != end) {
+        int inside = 0;
+        const int* list = b->h_lists.data() + b->steady_offset[slot];
+        for (int k = 0; k < end; ++k) inside += b->inst_filtered[list[k]];
+        b->inside_version = b->lists_version;
+        b->inside_end = end;
+        b->inside_filtered = inside;
+    }
+    return b->inside_filtered;
+}
+
+void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flags, bool proven_usable, bool filters_inside, hipStream_t stream)
+{
+    int counts[4];
+    steady_kind_counts(b, slot, proven_usable, counts);
     KernelCtx c = ctx;
     c.progress = nullptr;
     // one proven kind alone: its list may be a plain range of instances
@@ -814,7 +849,7 @@ void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, i
     ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
     const char* name = oalsfx_hip::launch_reverb_steady_kinds(c, slot, b->d_lists + b->steady_offset[slot], counts,
                                                               flags | ((debug_flags() & 0xFF) << 8) | ((debug_flags() & 0x100) ? oalsfx_hip::kNoCuMajor : 0),
-                                                              (debug_flags() & 0x1000000) != 0, stream);
+                                                              (debug_flags() & 0x1000000) != 0, filters_inside, stream);
     if (name) b->last_steady_kernel = name;
 }
 
@@ -936,6 +971,34 @@ bool check_fault(oalsfx_batch* b)
     return b->fail("Internal error: a reverb instance listed as proven steady was not; its buffer was left unprocessed.");
 }
 
+// What a slot launches for a chunk of n frames: how many instances on the ring-light kernels, on the steady-state reverb kernels, reverbs
+// in all, and which launch shape the steady ones take.
+struct SlotPlan {
+    int light, steady, reverbs;
+    bool use_steady, mixed, by_kind, proven_usable;
+};
+
+SlotPlan plan_slot(const oalsfx_batch* b, const KernelCtx& ctx, int s, int n, bool null_has_duty)
+{
+    SlotPlan p{};
+    for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) p.light += b->list_count[s][t];
+    // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state reverb kernel and the general
+    // reverb kernel
+    p.use_steady = steady_kernel_usable(ctx);
+    p.steady = p.use_steady ? b->fast_count[s] + b->slow_count[s] : 0;
+    p.reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
+    // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
+    p.mixed = p.light > 0 && p.steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
+    // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
+    const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
+    const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
+    // (round 3: the proven instances no longer wait for the last believed one of their slot: one grid serves every kind,
+    // k_reverb_steady_kinds, each workgroup on the build its instances need)
+    p.by_kind = p.use_steady && !p.mixed && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline;
+    p.proven_usable = gains_rest && !(debug_flags() & 0x200000);
+    return p;
+}
+
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
 {
     poll_exact(b);
@@ -977,24 +1040,49 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         ctx.raw_src = chunk_src;
         ctx.dst = dst + static_cast<size_t>(done) * b->channels;
         ctx.frames = n;
-        if (filtered) {
+        bool planes = filtered; // the pre-pass ran: the instances it covers read their sends from its planes (flag kFiltered)
+        // Single-slot batches: the steady-state reverb builds of the first two kinds filter their own sends (SF); the pre-pass then covers
+        // the rest of the slot's list only, or is not launched at all.
+        bool filters_inside = false;
+        if (filtered && b->slots == 1) {
+            const SlotPlan p0 = plan_slot(b, ctx, 0, n, true);
+            if (p0.by_kind && p0.steady > 0) {
+                int counts[4];
+                steady_kind_counts(b, 0, p0.proven_usable, counts);
+                const int inside = filters_inside_count(b, 0, counts);
+                if (inside > 0) {
+                    filters_inside = true;
+                    ctx.src_stride = static_cast<long long>(n) * b->channels;
+                    planes = inside < b->n_filtered;
+                    if (planes) {
+                        const int before = b->steady_offset[0], behind = before + counts[0] + counts[1];
+                        oalsfx_hip::launch_send_filters(ctx, chunk_src, ctx.io_stride, b->d_filtered, b->filtered_capacity, b->d_lists, before, stream);
+                        oalsfx_hip::launch_send_filters(ctx, chunk_src, ctx.io_stride, b->d_filtered, b->filtered_capacity, b->d_lists + behind, b->n - behind, stream);
+                    }
+                }
+            }
+        }
+        if (filters_inside) {
+            ctx.src = planes ? b->d_filtered : chunk_src;
+            if (!planes) ctx.src_stride = ctx.io_stride;
+        } else if (filtered) {
             // apply_filters for every send (reference src/oalsfxpp.cpp:2929-2965): planes of [instance][n][channels]
             ctx.src_stride = static_cast<long long>(n) * b->channels;
-            oalsfx_hip::launch_send_filters(ctx, chunk_src, ctx.io_stride, b->d_filtered, b->filtered_capacity, b->n, stream);
+            oalsfx_hip::launch_send_filters(ctx, chunk_src, ctx.io_stride, b->d_filtered, b->filtered_capacity, nullptr, b->n, stream);
             ctx.src = b->d_filtered;
         } else {
             ctx.src_stride = ctx.io_stride;
             ctx.src = chunk_src;
         }
-        ctx.wet_plane = filtered ? static_cast<long long>(b->filtered_capacity) : 0;
+        ctx.wet_plane = planes ? static_cast<long long>(b->filtered_capacity) : 0;
         for (int s = 0; s < b->slots; ++s) {
-            ctx.wet_src = filtered ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
+            ctx.wet_src = planes ? b->d_filtered + static_cast<size_t>(1 + s) * b->filtered_capacity : ctx.src;
             const int run = reverb_free_run(b, s);
             if (run >= 2 && !(debug_flags() & 0x8000000)) {
                 // slots s .. s+run-1 hold ring-light effects (or nothing) for every instance: one launch, one wavefront per
                 // instance, the slots in order inside it; the slot's list in type order lists every instance exactly once
                 const int run_flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s + run == b->slots ? oalsfx_hip::kLast : 0) |
-                                      (filtered ? oalsfx_hip::kFiltered : 0);
+                                      (planes ? oalsfx_hip::kFiltered : 0);
                 {
                     ScopedTiming timing(b, kTimedWaveEffects, stream);
                     oalsfx_hip::launch_wave_effects(ctx, s, run, b->d_lists + b->list_offset[s][OALSFX_NULL], b->n, nullptr, run_flags, stream);
@@ -1003,28 +1091,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 continue;
             }
             const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0) |
-                              (filtered ? oalsfx_hip::kFiltered : 0);
+                              (planes ? oalsfx_hip::kFiltered : 0);
             const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
-            int light = 0;
-            for (int t = null_has_duty ? 0 : 1; t < OALSFX_REVERB; ++t) light += b->list_count[s][t];
-            // the kernels of a slot work on disjoint instances: ring-light effects, the steady-state reverb kernel and the general
-            // reverb kernel
-            const bool use_steady = steady_kernel_usable(ctx);
-            const int steady = use_steady ? b->fast_count[s] + b->slow_count[s] : 0;
-            const int reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
-            // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
-            const bool mixed = light > 0 && steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
-            // the proven-steady builds: mono / stereo, whole tiles, a launch of their own
-            // ... and only when every steady instance of the slot is proven: a second steady launch beside it costs more than the
-            // believing builds cost the proven instances (4 send changes per buffer among 4096 reverbs: 92.8 against 68.2 us per step,
-            // scripts/send_change_bench.py; re-measured with the side launches off the critical path)
-            // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
-            const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
-            const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
-            // (round 3: the proven instances no longer wait for the last believed one of their slot: one grid serves every kind,
-            // k_reverb_steady_kinds, each workgroup on the build its instances need)
-            const bool by_kind = use_steady && !mixed && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline;
-            const bool proven_usable = gains_rest && !(debug_flags() & 0x200000);
+            const SlotPlan sp = plan_slot(b, ctx, s, n, null_has_duty);
+            const int light = sp.light, steady = sp.steady, reverbs = sp.reverbs;
+            const bool use_steady = sp.use_steady, mixed = sp.mixed, by_kind = sp.by_kind, proven_usable = sp.proven_usable;
             // parts: ring-light effects | (unused) | steady reverbs | general reverbs
             bool part_on[4] = {light > 0 && !mixed, false, steady > 0, reverbs - steady > 0};
             int parts = 0;
@@ -1051,7 +1122,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 } else if (g == 2 && mixed) {
                     launch_mixed_part(b, ctx, s, flags, gs);
                 } else if (g == 2 && by_kind) {
-                    launch_reverb_kinds_part(b, ctx, s, flags, proven_usable, gs);
+                    launch_reverb_kinds_part(b, ctx, s, flags, proven_usable, filters_inside, gs);
                 } else if (g == 2) {
                     // ragged calls, more than two channels, the timeline build: one launch of the believing builds for all of them
                     launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], steady, false, gs);
@@ -1131,6 +1202,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->h_rings.assign(total, nullptr);
     b->ring_floats.assign(total, 0);
     b->inst_dirty.assign(n_instances, 0);
+    b->inst_filtered.assign(n_instances, 0);
     b->touched.assign(n_instances, 0);
     b->since_update.assign(total, 0);
     b->slot_class.assign(total, 0);

@@ -91,6 +91,8 @@ enum : int {
     kFirst = 1, // slot 0: start from the dry mix of the input instead of reading mixbuf
     kLast = 2,  // last slot: write the interleaved output instead of mixbuf
     kNoCuMajor = 32, // experiment (OALSFX_DEBUG_FLAGS 0x100): grids of several kinds in plain workgroup order
+    kFilterInside = 64, // the steady-state reverb builds that have the send filters inside (SF) apply them themselves for the instances that
+                        // have one switched on: the pre-pass leaves those instances out
     kFiltered = 16, // the send-filter pre-pass (k_send_filters) ran: for the instances with a filter switched on, the planes at
                     // filtered_src / wet planes hold their sends' inputs and their filter histories are up to date
 };
@@ -113,7 +115,10 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // of one to two tiles; [2] proven, shorter taps or a modulated late line; [3] believed steady or in a transition the XF build follows.
 // One kind alone runs its own lean kernel, several share one grid whose workgroups take the build of their kind.
 // no_fallback: the believed kind without the general path inside (the host predicts the kernel's test; a miss is counted in ctx.fault).
-const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, hipStream_t stream);
+// filters_inside: some instance of the first two kinds has a send filter switched on and the batch has one slot: those kinds run the SF
+// builds (send filters inside, flag kFilterInside), and the pre-pass need not know them.
+const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
+                                       hipStream_t stream);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments
@@ -125,7 +130,8 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
                        const WaveSegments& seg, int flags, bool proven, hipStream_t stream);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
-void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
+// `list` (may be nullptr: instances 0 .. instances - 1): the instances to look at (those among them without a filter are skipped)
+void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, const int* list, int instances,
                          hipStream_t stream);
 // record k of `packed` (count records of record_bytes, a multiple of 4) goes to slot indices[k] of the device array `dst`
 void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, const int* indices, int count, hipStream_t stream);

@@ -287,12 +287,22 @@ __device__ __forceinline__ void lds_barrier()
 // cross-fading tiles request the taps being faded in at the top of the tile, behind the previous tile's stores, and mix the two sets
 // per sample (where a set's source lies inside the tile, after that set's own hand-over); the gains that ramp are stepped serially (the running sum is not a closed form in
 // floating point) by the wavefront's own lanes, one per gain, into rows of the late half that are idle in S5.
+// SF (the FP plain and HY builds, mono / stereo, single-slot batches): the send shelf filters inside (reference apply_filters,
+// src/oalsfxpp.cpp:3101-3143, at most two biquads per send and input channel) for the instances that have one switched on, instead of
+// the pre-pass kernel and its planes.  The tile loop is skewed once more: iteration it filters the frame of tile it + 1 -- feed-forward
+// sums with lane = frame in S1 and S3, the two recurrences on 4 x (sends x channels) lanes of the wavefronts that idle in S2 and S4 --
+// beside the input half of tile it, which takes the filtered rows instead of the raw frame, and the late half of tile it - 1.  No
+// barrier is added; a workgroup with such an instance runs one iteration more.
 // RG (a variant of the ST build): calls that are not a whole number of tiles.  The last tile holds L < 64 samples: its lanes
 // from L on compute along but store nothing, the recurrences and the modulation smoother stop at L, and the histories are
 // taken from sample L - 1.
 
 // LDS of one workgroup of the cooperative kernel
-template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true>
+// SF: the send filters inside (the FP plain and HY builds of single-slot batches): per wave two rows per send and input channel -- the
+// first shelf's feed-forward sums / output, the second shelf's -- and 64 floats of coefficients, edge samples and histories
+namespace sfm { enum { TAB = 0 /* [send][12] */, EDGE = 24 /* [channel][4]: samples 0, 1, 62, 63 of the tile being filtered */, HIST = 32 /* [row][6] */, SIZE = 64 }; }
+
+template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true, bool SF = false>
 struct SteadyShared {
     static constexpr bool MC = CH > 2;
     static constexpr int kMcBase = ut::SIZE + 8 * kRow; // multichannel tables behind the hand-over rows (the modulation row shares the first of
@@ -308,6 +318,9 @@ struct SteadyShared {
     alignas(16) float lds_all[NW][kFloats];
     float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
     unsigned tapn_all[FP ? 1 : NW][24]; // XF: [wave][group * 4 + line]: the taps being faded in, as byte distances like ut::TAP4
+    alignas(16) float sf_rows[SF ? NW : 1][SF ? 4 * CH : 1][kRow]; // SF: [wave][stage * 2 * CH + send * CH + channel]
+    float sf_misc[SF ? NW : 1][sfm::SIZE];
+    int sf_all[NW]; // SF: which instances of the group filter their sends in here
     int go_all[NW];
     int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
 };
@@ -319,12 +332,14 @@ struct SteadyShared {
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
 // kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, class SH>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
 {
     static_assert(!FP || (CH <= 2 && !RG), "the proven-steady builds: mono / stereo, whole tiles");
     static_assert(!XF || (CH <= 2 && !RG && !FP && HY && MD && ST), "the cross-fading build: a variant of the most general one, mono / stereo, whole tiles");
+    static_assert(!SF || (FP && !MD && !ST && NW == 4), "send filters inside: the FP plain and HY builds");
+    constexpr int kSfRows = 2 * CH; // SF: rows per stage = sends (direct, this slot's auxiliary) x input channels
     // XF: dword offset (from the table) of the taps being faded in: a second tap table with ut::TAP4's layout, in the workgroup's own array
     const int kTapN = static_cast<int>(reinterpret_cast<float*>(&sh.tapn_all[FP ? 0 : wib_of(threadIdx.x)][0]) - (sh.lds_all[wib_of(threadIdx.x)] + kSteadyGroups * 4 * kRow));
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
@@ -613,8 +628,34 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     }
     } // !hit
     stamp(); // [1] hot record or descriptors read, steady-state test done, tables written
+    // SF: this instance filters its sends in here (the host says so for the launch: single-slot batch, every such instance on an SF build)
+    const bool sf = SF && go && first && (flags & kFilterInside) != 0 && has_filter;
+    float* const sfmisc = sh.sf_misc[SF ? wib : 0];
+    auto sfrow = [&](int stage, int r) -> float* { return sh.sf_rows[SF ? wib : 0][SF ? stage * kSfRows + r : 0]; };
+    if constexpr (SF) {
+        if (lane == 0) sh.sf_all[wib] = sf ? 1 : 0;
+        if (sf) {
+            // coefficients per send (lane 0: the direct send, lane 1: this slot's), histories per (send, channel)
+            const oalsfx_source_params& SGp = ctx.source[inst];
+            const oalsfx_source_state& SGs = ctx.source_state[inst];
+            if (lane < 2) {
+                const oalsfx_send_params& sp = lane == 0 ? SGp.direct : SGp.aux[slot];
+                float* t = sfmisc + sfm::TAB + 12 * lane;
+                t[0] = sp.lp.b0; t[1] = sp.lp.b1; t[2] = sp.lp.b2; t[3] = sp.hp.b0; t[4] = sp.hp.b1; t[5] = sp.hp.b2;
+                t[6] = sp.lp.a1; t[7] = sp.lp.a2; t[8] = sp.hp.a1; t[9] = sp.hp.a2;
+                const bool enabled = lane == 0 || sp.out_channels != 0;
+                reinterpret_cast<int*>(t)[10] = enabled ? (((sp.filter_type & OALSFX_AF_LOW_PASS) ? 1 : 0) | ((sp.filter_type & OALSFX_AF_HIGH_PASS) ? 2 : 0) | 4) : 0;
+            }
+            if (lane < kSfRows) {
+                const int sd = lane / CH, c = lane % CH, at = sd ? 1 + slot : 0;
+                const oalsfx_hist_t lp = SGs.lp[at][c], hp = SGs.hp[at][c];
+                float* h = sfmisc + sfm::HIST + 6 * lane; // x: input, y: output of the first shelf = input of the second, z: output of the second
+                h[0] = lp.x[0]; h[1] = lp.x[1]; h[2] = lp.y[0]; h[3] = lp.y[1]; h[4] = hp.y[0]; h[5] = hp.y[1];
+            }
+        }
+    }
     // after the send-filter pre-pass an instance with a filter reads its sends' planes, any other instance the raw input
-    const bool filtered = (flags & kFiltered) != 0 && has_filter;
+    const bool filtered = !sf && (flags & kFiltered) != 0 && has_filter;
     const float* src = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
     const float* wsrc = src;
     if (filtered) {
@@ -740,8 +781,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // [4]
     bool any_go = false;
     bool any_eax = false; // the second-shelf phases (and their barriers) exist when some instance of the group needs them
+    bool any_sf = false;  // SF: some instance of the group filters its sends in here: the loop starts one iteration earlier
 #pragma unroll
-    for (int k = 0; k < NW; ++k) { any_go |= go_all[k] != 0; any_eax |= eax_all[k] != 0; }
+    for (int k = 0; k < NW; ++k) { any_go |= go_all[k] != 0; any_eax |= eax_all[k] != 0; if (SF) any_sf |= sh.sf_all[k] != 0; }
     const bool chain_on = (lane < 4 * NW) && go_all[cw] != 0;
     const bool chain2_on = chain_on && eax_all[cw] != 0;
     // which wavefront runs chain phase p: rotated per workgroup so that the co-resident workgroups of a CU do not all
@@ -764,9 +806,9 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned long long ramp_mask = 0ULL;
     // ... and where the stepped gains of a tile go: rows of the late half that are idle in S5, and hand-over rows
     auto grow = [&](int q) -> float* { return q < 12 ? rowL(q >> 2, q & 3) + 4 : utf + ut::SIZE + (2 + q - 12) * kRow + 4; };
-    for (int it = 0; it <= tiles && tiles > 0; ++it) {
-        const int ta = it, tb = it - 1;
-        const bool has_a = ta < tiles, has_b = tb >= 0;
+    for (int it = (SF && any_sf) ? -1 : 0; it <= tiles && tiles > 0; ++it) {
+        const int ta = it, tb = it - 1, tc = it + 1; // tc (SF): the tile whose frame goes through the send filters in this iteration
+        const bool has_a = ta >= 0 && ta < tiles, has_b = tb >= 0, has_c = SF && tc < tiles;
         const int pos_a = (ta << 6) + lane, pos_b = (tb << 6) + lane;
         // RG, the build for calls that are not a whole number of tiles: the last tile holds fewer samples; its lanes from L on
         // compute along but store nothing, and the recurrences stop at L.  (Its own build: with L a variable the chain loops and
@@ -953,13 +995,18 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
         // ---------------- S1, input half: P1(ta): inputs, A-format, feed-forward half of the first shelf ----------------
         if (go && has_a) {
-            const float in[2] = {n_in0, n_in1};
-            const float win[2] = {filtered ? n_w0 : n_in0, filtered ? n_w1 : n_in1}; // what the auxiliary send sees
+            float in[2] = {n_in0, n_in1};
+            float win[2] = {filtered ? n_w0 : n_in0, filtered ? n_w1 : n_in1}; // what the auxiliary send sees
+            if (SF && sf) {
+                // send filters inside: the frame as the two sends see it, left in the second shelves' rows by the iteration before
+#pragma unroll
+                for (int c = 0; c < (MC ? 0 : CH); ++c) { in[c] = sfrow(1, c)[4 + lane]; win[c] = sfrow(1, CH + c)[4 + lane]; }
+            }
             float inv[MC ? 8 : 1], winv[MC ? 8 : 1];
 #pragma unroll
             for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
-            if (ta + 1 < tiles) issue_input(pos_a + 64); // the next tile's frame, now that this one's is in `in`
-            if (FP && ta + 1 == tiles) {
+            if (!(SF && sf) && ta + 1 < tiles) issue_input(pos_a + 64); // the next tile's frame, now that this one's is in `in`
+            if (FP && !(SF && sf) && ta + 1 == tiles) {
                 // the call's last two frames, for the histories of the pass-through send filters (no loads in the epilogue)
 #pragma unroll
                 for (int c = 0; c < (MC ? 0 : CH); ++c) {
@@ -1029,6 +1076,28 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 ch[coop::LPX1] = rowI(0, lane)[4 + La - 2]; ch[coop::LPX0] = rowI(0, lane)[4 + La - 1]; // La == 1: [3] is the old newest sample
             }
         }
+        // ---------------- S1, SF: the frame of tile tc through the first shelves' feed-forward halves (lane = frame) ----------------
+        if (SF && sf && has_c) {
+            const float x[2] = {n_in0, n_in1};
+            if (tc + 1 < tiles) issue_input(((tc + 1) << 6) + lane);
+#pragma unroll
+            for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                // samples 0 and 1 need the send's own input history, which the recurrence lane holds: it writes them (and takes the tile's
+                // last two inputs for the next tile's) from these edge samples
+                if (lane < 2) sfmisc[sfm::EDGE + 4 * c + lane] = x[c];
+                if (lane >= 62) sfmisc[sfm::EDGE + 4 * c + lane - 60] = x[c];
+                const float xm1 = __shfl_up(x[c], 1), xm2 = __shfl_up(x[c], 2);
+#pragma unroll
+                for (int sd = 0; sd < 2; ++sd) {
+                    const float* t = sfmisc + sfm::TAB + 12 * sd;
+                    const int mode = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t)[10]);
+                    if (!(mode & 4)) continue;
+                    float v = x[c];
+                    if ((mode & 1) && lane >= 2) v = (t[0] * x[c]) + (t[1] * xm1) + (t[2] * xm2);
+                    sfrow(0, sd * CH + c)[4 + lane] = v;
+                }
+            }
+        }
         if (go && has_a) {
             // (all of a tile's requests at the top of S1, or the late all-pass group here instead of in S3: measured, no faster)
             issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta)); // on their way while the chain phases run
@@ -1048,6 +1117,28 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
             __builtin_amdgcn_s_setprio(0);
         }
+        if (SF && any_sf && duty == 1 && has_c && lane < NW * kSfRows) {
+            // SF: the first send shelves' recurrences of tile tc, lane = (instance, send, channel), on a wavefront that idles in S2
+            const int cwx = lane / kSfRows, rr = lane % kSfRows, sd = rr / CH, c = rr % CH;
+            float* m = sh.sf_misc[SF ? cwx : 0];
+            const float* t = m + sfm::TAB + 12 * sd;
+            const int mode = sh.sf_all[cwx] ? reinterpret_cast<const int*>(t)[10] : 0;
+            if (mode & 4) {
+                float* h = m + sfm::HIST + 6 * rr;
+                float* wrow = sh.sf_rows[SF ? cwx : 0][SF ? rr : 0];
+                const float* e = m + sfm::EDGE + 4 * c; // the tile's input samples 0, 1, 62, 63 of this channel
+                float y1 = h[2], y2 = h[3];
+                if (mode & 1) {
+                    const float x1 = h[0], x2 = h[1];
+                    wrow[4] = (t[0] * e[0]) + (t[1] * x1) + (t[2] * x2);
+                    wrow[5] = (t[0] * e[1]) + (t[1] * e[0]) + (t[2] * x1);
+                }
+                wrow[2] = y2; wrow[3] = y1; // the second shelf's feed-forward sums read its input history here
+                if (mode & 1) biquad_chain(wrow, wrow, 64, t[6], t[7], y1, y2);
+                else { y1 = e[3]; y2 = e[2]; } // a shelf that is off passes its input through and lets its history follow (process_pass_through)
+                h[0] = e[3]; h[1] = e[2]; h[2] = y1; h[3] = y2;
+            }
+        }
         if (duty == ((NW == 2) ? 0 : 2 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O1];
@@ -1066,6 +1157,22 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         if (go && has_a) {
             issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta));
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SF && sf && has_c) {
+            // SF: the second send shelves' feed-forward halves of tile tc (lane = frame): from the first shelves' rows to their own
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const float* t = sfmisc + sfm::TAB + 12 * sd;
+                const int mode = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(t)[10]);
+                if (!(mode & 4)) continue;
+#pragma unroll
+                for (int c = 0; c < (MC ? 0 : CH); ++c) {
+                    const float* y = sfrow(0, sd * CH + c) + 4 + lane;
+                    float v = y[0];
+                    if ((mode & 6) == 6) v = (t[3] * y[0]) + (t[4] * y[-1]) + (t[5] * y[-2]);
+                    sfrow(1, sd * CH + c)[4 + lane] = v;
+                }
+            }
         }
         if (any_eax) {
             if (go && eax && has_a) {
@@ -1097,6 +1204,21 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 biquad_chain(crowI1, crowI0, La, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
                 __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if (SF && any_sf && duty == 0 && has_c && lane < NW * kSfRows) {
+            // SF: the second send shelves' recurrences of tile tc, on a wavefront that idles in S4
+            const int cwx = lane / kSfRows, rr = lane % kSfRows, sd = rr / CH;
+            float* m = sh.sf_misc[SF ? cwx : 0];
+            const float* t = m + sfm::TAB + 12 * sd;
+            const int mode = sh.sf_all[cwx] ? reinterpret_cast<const int*>(t)[10] : 0;
+            if (mode & 4) {
+                float* h = m + sfm::HIST + 6 * rr;
+                float z1 = h[4], z2 = h[5];
+                float* zrow = sh.sf_rows[SF ? cwx : 0][SF ? kSfRows + rr : 0];
+                if (mode & 2) biquad_chain(zrow, zrow, 64, t[8], t[9], z1, z2);
+                else { z1 = h[2]; z2 = h[3]; }
+                h[4] = z1; h[5] = z2;
             }
         }
         if (duty == ((NW == 2) ? 1 : 3 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain_on && has_b) {
@@ -1289,7 +1411,21 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 if (lane == 0) ctx.exact[sidx] = fade_over ? level : 0u;
             }
         }
-        if (FP) {
+        if (SF && sf) {
+            // the send filters' histories as the recurrence lanes left them (the second shelf's input history is the first one's output)
+            if (lane < kSfRows) {
+                const int sd = lane / CH, c = lane % CH, at = sd ? 1 + slot : 0;
+                if (reinterpret_cast<const int*>(sfmisc + sfm::TAB + 12 * sd)[10] & 4) {
+                    const float* h = sfmisc + sfm::HIST + 6 * lane;
+                    oalsfx_source_state& SGs = ctx.source_state[inst];
+                    oalsfx_hist_t lp, hp;
+                    lp.x[0] = h[0]; lp.x[1] = h[1]; lp.y[0] = h[2]; lp.y[1] = h[3];
+                    hp.x[0] = h[2]; hp.x[1] = h[3]; hp.y[0] = h[4]; hp.y[1] = h[5];
+                    SGs.lp[at][c] = lp;
+                    SGs.hp[at][c] = hp;
+                }
+            }
+        } else if (FP) {
             if (first && !filtered && lane < nch)
                 send_history_follow_values(ctx, inst, lane, send_mask, lane == 0 ? hist_new[0] : hist_new[CH - 1], lane == 0 ? hist_old[0] : hist_old[CH - 1]);
         } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
@@ -1329,11 +1465,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
-    __shared__ SteadyShared<CH, NW, FP, MD, ST> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    __shared__ SteadyShared<CH, NW, FP, MD, ST, SF> sh;
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // One grid for a slot's steady reverbs of several kinds (mono / stereo, whole tiles).  The host orders the slot's list by kind and the
@@ -1346,11 +1482,11 @@ struct SteadyKinds {
     __host__ __device__ int groups(int k) const { return (count[k] + 3) >> 2; }
 };
 
-template <int CH, bool NF>
+template <int CH, bool NF, bool SF>
 __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, int slot, const int* __restrict__ list, SteadyKinds kinds, int flags)
 {
     union Shared {
-        SteadyShared<CH, 4, true, false, false> lean;    // plain and HY
+        SteadyShared<CH, 4, true, false, false, SF> lean; // plain and HY (SF: with the send filters inside)
         SteadyShared<CH, 4, true, true, true> general;   // ST (includes MD)
         SteadyShared<CH, 4, false, true, true> believed; // XF
     };
@@ -1358,13 +1494,13 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, i
     // in CU-major order: the workgroups that share a CU run the same build (as far as the kinds' sizes allow)
     int group = (flags & kNoCuMajor) ? static_cast<int>(blockIdx.x) : cu_major_position(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
     if (group < kinds.groups(0)) {
-        reverb_steady_group<CH, 4, false, false, false, false, false, true>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
+        reverb_steady_group<CH, 4, false, false, false, false, false, true, false, false, SF>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
         return;
     }
     group -= kinds.groups(0);
     list += kinds.count[0];
     if (group < kinds.groups(1)) {
-        reverb_steady_group<CH, 4, false, true, false, false, false, true>(ctx, slot, list, kinds.count[1], flags, group, sh.lean);
+        reverb_steady_group<CH, 4, false, true, false, false, false, true, false, false, SF>(ctx, slot, list, kinds.count[1], flags, group, sh.lean);
         return;
     }
     group -= kinds.groups(1);
@@ -2113,14 +2249,26 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // The steady reverbs of a slot by kind (mono / stereo, whole tiles): counts[0] proven with every tap two tiles away, [1] proven with a
 // tap of one to two tiles, [2] proven with shorter taps or a modulated late line, [3] believed steady or in a transition the XF build
 // follows; `list` holds them in this order.  One kind alone takes its lean kernel, several share the grid of k_reverb_steady_kinds.
-const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, hipStream_t stream)
+const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
+                                       hipStream_t stream)
 {
     const int total = counts[0] + counts[1] + counts[2] + counts[3];
     if (total <= 0) return nullptr;
     int populated = 0, only = 0;
     for (int k = 0; k < 4; ++k)
         if (counts[k] > 0) { ++populated; only = k; }
+    const bool sf = filters_inside && ctx.slots == 1 && counts[0] + counts[1] > 0;
+    if (sf) flags |= kFilterInside;
     if (populated == 1 && !(only == 3 && no_fallback)) {
+        if (sf) {
+            // one of the first two kinds alone, with the send filters inside: template arguments channels, wavefronts, TL, HY, MD, ST, RG, FP, XF, NF, SF
+            const dim3 grid((total + 3) / 4), block(256);
+            if (ctx.channels == 1 && only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true>"; }
+            if (ctx.channels == 1) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true>"; }
+            if (only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true>"; }
+            OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags);
+            return "k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true>";
+        }
         // (close_taps / modulated / short_taps select the FP build of the kind; the believed kind alone: the XF build with the general path inside)
         return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream);
     }
@@ -2130,14 +2278,20 @@ const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int
     int groups = 0;
     for (int k = 0; k < 4; ++k) { kinds.count[k] = counts[k]; groups += kinds.groups(k); }
     const dim3 grid(groups), block(256);
+#define OALSFX_KINDS(...)                                                                                  \
+    do {                                                                                                   \
+        OALSFX_LAUNCH((k_reverb_steady_kinds<__VA_ARGS__>), grid, block, stream, c, slot, list, kinds, flags); \
+        return "k_reverb_steady_kinds<" #__VA_ARGS__ ">";                                                  \
+    } while (0)
     if (c.channels == 1) {
-        if (no_fallback) { OALSFX_LAUNCH((k_reverb_steady_kinds<1, true>), grid, block, stream, c, slot, list, kinds, flags); return "k_reverb_steady_kinds<1, true>"; }
-        OALSFX_LAUNCH((k_reverb_steady_kinds<1, false>), grid, block, stream, c, slot, list, kinds, flags);
-        return "k_reverb_steady_kinds<1, false>";
+        if (no_fallback) OALSFX_KINDS(1, true, false);
+        if (sf) OALSFX_KINDS(1, false, true);
+        OALSFX_KINDS(1, false, false);
     }
-    if (no_fallback) { OALSFX_LAUNCH((k_reverb_steady_kinds<2, true>), grid, block, stream, c, slot, list, kinds, flags); return "k_reverb_steady_kinds<2, true>"; }
-    OALSFX_LAUNCH((k_reverb_steady_kinds<2, false>), grid, block, stream, c, slot, list, kinds, flags);
-    return "k_reverb_steady_kinds<2, false>";
+    if (no_fallback) OALSFX_KINDS(2, true, false);
+    if (sf) OALSFX_KINDS(2, false, true);
+    OALSFX_KINDS(2, false, false);
+#undef OALSFX_KINDS
 }
 
 // Everything else: cross-fades, modulation, gain ramps, taps closer than a tile, partial tiles, more than two channels.

@@ -72,7 +72,7 @@ __device__ __forceinline__ void filter_recurrence(float* row, int n, float a1, f
 }
 
 __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float* __restrict__ src_all, long long src_stride,
-                                                      float* __restrict__ filtered, size_t send_floats, int instances)
+                                                      float* __restrict__ filtered, size_t send_floats, const int* __restrict__ list, int instances)
 {
     __shared__ __attribute__((aligned(16))) float filter_lds[4][kFilterRowsPerWave * kFilterRow + kFilterTable];
     const int lane = threadIdx.x & 63;
@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
     const int ipw = filter_instances_per_wave(channels, ctx.slots);
     const int first = (blockIdx.x * 4 + wib) * ipw;
     if (first >= instances) return; // whole wavefronts leave; no workgroup barrier in this kernel
-    // which of this wavefront's instances have a filter switched on
-    const unsigned long long todo_mask = __ballot(lane < ipw && first + lane < instances && instance_has_send_filter(ctx, first + lane));
+    // the wavefront's instances: entries first, first + 1, ... of the list (or the instances of those numbers), and which of them have a
+    // filter switched on
+    auto entry = [&](int k) -> int { return first + k < instances ? (list ? list[first + k] : first + k) : 0; };
+    const int inst_of[kFilterInstances] = {__builtin_amdgcn_readfirstlane(entry(0)), __builtin_amdgcn_readfirstlane(entry(1))};
+    const unsigned long long todo_mask = __ballot(lane < ipw && first + lane < instances && instance_has_send_filter(ctx, lane == 0 ? inst_of[0] : inst_of[1]));
     if (todo_mask == 0ULL) return;
     float* lds = filter_lds[wib];
     float* table = lds + kFilterRowsPerWave * kFilterRow;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
     const int sub = lane / chains, r = lane % chains;
     const int send = r / channels, c = r % channels;
     const bool chain_lane = sub < ipw && ((todo_mask >> sub) & 1ULL) != 0;
-    const int my_inst = chain_lane ? first + sub : first;
+    const int my_inst = (chain_lane && sub == 1) ? inst_of[1] : inst_of[0];
     const oalsfx_source_params& P = ctx.source[my_inst];
     oalsfx_source_state& S = ctx.source_state[my_inst];
     const oalsfx_send_params* spp = &P.direct;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
         for (int k = 0; k < kFilterInstances; ++k) {
             ahead[k] = make_float2(0.0F, 0.0F);
             if (k >= ipw || !((todo_mask >> k) & 1ULL) || base + lane >= frames) continue;
-            const float* src = src_all + static_cast<size_t>(first + k) * src_stride;
+            const float* src = src_all + static_cast<size_t>(inst_of[k]) * src_stride;
             const size_t f = static_cast<size_t>(base + lane);
             if (channels == 2) ahead[k] = *reinterpret_cast<const float2*>(src + f * 2);
             else if (channels == 1) ahead[k].x = src[f];
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
         } else {
             for (int k = 0; k < ipw; ++k) {
                 if (!((todo_mask >> k) & 1ULL) || lane >= L) continue;
-                const float* src = src_all + static_cast<size_t>(first + k) * src_stride;
+                const float* src = src_all + static_cast<size_t>((k == 1 ? inst_of[1] : inst_of[0])) * src_stride;
                 float* in_rows = lds + k * rows * kFilterRow;
                 const size_t f = static_cast<size_t>(base + lane);
                 for (int ch = 0; ch < channels; ++ch) in_rows[ch * kFilterRow + 4 + lane] = src[f * channels + ch];
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
         // ---- 6. the filtered planes, lane = frame ----
         for (int k = 0; k < ipw; ++k) {
             if (!((todo_mask >> k) & 1ULL) || lane >= L) continue;
-            const int inst = first + k;
+            const int inst = (k == 1 ? inst_of[1] : inst_of[0]);
             const size_t f = static_cast<size_t>(base + lane);
             for (int sd = 0; sd < sends; ++sd) {
                 if (!(reinterpret_cast<const int*>(table + (k * sends + sd) * 8)[6] & 4)) continue;
@@ -251,13 +254,13 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
     }
 }
 
-void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, int instances,
+void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, const int* list, int instances,
                          hipStream_t stream)
 {
     if (instances <= 0 || ctx.frames <= 0) return;
     const int ipw = filter_instances_per_wave(ctx.channels, ctx.slots);
     const int waves = (instances + ipw - 1) / ipw;
-    hipLaunchKernelGGL(k_send_filters, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, instances);
+    hipLaunchKernelGGL(k_send_filters, dim3((waves + 3) / 4), dim3(256), 0, stream, ctx, src, src_stride, filtered, send_floats, list, instances);
 }
 
 // ---- synthetic benchmark input, generated in device memory ----
