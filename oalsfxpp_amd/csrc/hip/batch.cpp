@@ -243,7 +243,7 @@ constexpr int kSettleFrames = OALSFX_RV_FADE_SAMPLES; // the cross-fade (128 fra
 enum : uint8_t {
     kClassReverb = 1,  // reverb or EAX reverb
     kClassSteady = 2,  // parameters the steady-state kernel builds accept
-    kClassClose = 4,   // shortest tap distance 64..127 samples
+    kClassClose = 4,   // shortest tap distance 64 .. kPlainMinTap - 1 samples (the HY builds)
     kClassShort = 8,   // shortest tap distance below 64 samples
     kClassModulated = 16,
 };
@@ -263,7 +263,7 @@ uint8_t classify_slot(const oalsfx_slot_params& sp)
             cls &= static_cast<uint8_t>(~kClassSteady);
         lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
     }
-    if (lo >= 64 && lo < 128) cls |= kClassClose;
+    if (lo >= 64 && lo < static_cast<int>(oalsfx_hip::kPlainMinTap)) cls |= kClassClose;
     if (lo < 64) cls |= kClassShort;
     if (p.mod_depth != 0.0F) cls |= kClassModulated;
     return cls;

@@ -98,6 +98,10 @@ enum : int {
 };
 
 constexpr int kWave = 64;
+// The plain build of the steady-state reverb kernel takes instances whose every tap is at least this many samples from where it is
+// written (late taps: from the late feed): three tiles, so that the aligned windows it requests a tile ahead (reverb.hip, OALSFX_AW)
+// never reach samples that are still being written.  The host sorts proven instances into kinds by the same number (batch.cpp).
+constexpr unsigned kPlainMinTap = 192;
 
 // ---- launchers (defined next to their kernels) ----
 // The host splits every reverb list into the instances it believes steady and the rest (a speed hint: the steady-state

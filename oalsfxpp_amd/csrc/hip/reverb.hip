@@ -127,6 +127,19 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 #ifndef OALSFX_NT
 #define OALSFX_NT 3
 #endif
+// Aligned windows for the long rings' taps (the plain FP build: every tap at least two tiles away, requested a tile ahead).  A tap's 64
+// samples start anywhere in a 128-byte line, so a wavefront's request touches three lines and every interior line is fetched by two
+// consecutive tiles; with the non-temporal hints nothing keeps it in a cache in between.  Instead: request the 256-byte-aligned window
+// that holds the end of what the tile needs, keep the window before it in a register per stream, and take each lane's sample from one
+// of the two with a lane rotation (ds_bpermute).  Two lines per stream and tile instead of three, one window more per launch.
+// The window requested for a tile reaches up to 63 samples past what the tile needs -- samples the *next* tile needs --, and it is
+// requested a tile ahead: so every tap of such an instance must be three tiles away (kPlainMinTap, which host and device share).
+// Measured (scripts/ab_libs.py, profiles/r03g_aligned_windows/): 256-frame calls 43.9 -> 42.3 us (-3.5 %), 512-frame calls -8.5 %,
+// 2048-frame calls 333.8 -> 297.6 us (-10.9 %: 37.2 us per 256 frames, 0.73 of the roofline).
+#ifndef OALSFX_AW
+#define OALSFX_AW 1
+#endif
+static_assert(!OALSFX_AW || kPlainMinTap >= 192, "aligned windows: a window requested a tile ahead may reach 63 samples past its tile's taps");
 template <int R> struct RingId { static constexpr int value = R; };
 constexpr bool long_ring(int r) { return r == OALSFX_RV_MAIN || r == OALSFX_RV_EARLY_LINE || r == OALSFX_RV_LATE_LINE; }
 // (the ring is a template argument: decided at run time, the two loads of one address are merged before the ring is known and the hint is lost)
@@ -526,7 +539,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // shortest distance accepted per group (ST build only)
         // (ST: early and late taps and the early line of any length, all-pass offsets from four samples -- up to fifteen evaluations ahead
         // per tile --, the late line a whole tile: its loop runs through the T60 chain phases)
-        const unsigned shortest = !ST ? (HY ? 256u : 512u) : (grp == 0 || grp == 2 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 16u : 256u;
+        const unsigned shortest = !ST ? (HY ? 256u : (FP ? 4u * kPlainMinTap : 512u)) : (grp == 0 || grp == 2 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 16u : 256u;
         if (__ballot(tp >= shortest + feed4 && tpn >= shortest + feed4) != ~0ULL) go = false;
         if (ST) {
             const unsigned long long in_tile = __ballot(lane < 24 && (tp < 256u + feed4 || tpn < 256u + feed4));
@@ -686,6 +699,37 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         v.w = ld_ring<r>(slab_b, ((t4x - d.w) & bm) | lo.w);
         return v;
     };
+    // AW: the aligned windows of the long rings' four tap groups (early taps, early line, late taps, late line)
+    constexpr bool AW = OALSFX_AW && FP && !HY && !MD && !ST && !MC && !XF;
+    v4f w_e = {0, 0, 0, 0}, w_el = w_e, w_lt = w_e, w_ll = w_e; // per group: the window before the one requested last
+    // the window [A + 256, A + 512) for the tile whose first sample stands at byte position tile4, A = (tile4 - tap) rounded down to 256
+    auto load4w = [&](unsigned tile4, int group, auto ring) -> v4f {
+        constexpr int r = decltype(ring)::value;
+        const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+        const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+        const unsigned bm = utu[ut::BMASK + r];
+        const unsigned l4 = 256u + 4u * static_cast<unsigned>(lane);
+        v4f v;
+        v.x = ld_ring<r>(slab_b, ((((tile4 - d.x) & ~255u) + l4) & bm) | lo.x);
+        v.y = ld_ring<r>(slab_b, ((((tile4 - d.y) & ~255u) + l4) & bm) | lo.y);
+        v.z = ld_ring<r>(slab_b, ((((tile4 - d.z) & ~255u) + l4) & bm) | lo.z);
+        v.w = ld_ring<r>(slab_b, ((((tile4 - d.w) & ~255u) + l4) & bm) | lo.w);
+        return v;
+    };
+    // lane L's sample stands k + L samples into the two windows, k = (tile4 - tap) % 256 / 4
+    auto rotate4 = [&](const v4f& before, const v4f& last, unsigned tile4, int group) -> v4f {
+        const v4u d = *reinterpret_cast<const v4u*>(utu + ut::TAP4 + 4 * group);
+        auto one = [&](float b, float l, unsigned dj) -> float {
+            // (lane j holds entry j of either window; entries k.. of the one before and ..k-1 of the last are wanted: merged per lane first,
+            // then one rotation by k lanes)
+            const int k = static_cast<int>(((tile4 - dj) & 255u) >> 2);
+            const float merged = lane >= k ? b : l;
+            return __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(((lane + k) & 63) << 2, static_cast<int>(__float_as_uint(merged)))));
+        };
+        v4f v;
+        v.x = one(before.x, last.x, d.x); v.y = one(before.y, last.y, d.y); v.z = one(before.z, last.z, d.z); v.w = one(before.w, last.w, d.w);
+        return v;
+    };
     // modulated late line (reference calc_modulation_delays, src/oalsfxpp.cpp:7443-7470): delay of this lane's sample in
     // the tile after the ones already prepared; the smoother's chain is strictly sequential, tile after tile
     // ST build: 8 hand-over rows behind the table; the modulation smoother's row (MD) lives only inside next_mod_delays and shares the first
@@ -743,10 +787,18 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     };
     // the ring requests of a tile in three parts (S1, S3, S5 of the iteration before its late half)
     auto issue_taps_a = [&](unsigned t4x, int base) {
-        if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, RingId<OALSFX_RV_MAIN>{}, base);
+        if (AW) n_e = load4w(t4x - 4u * static_cast<unsigned>(lane), 0, RingId<OALSFX_RV_MAIN>{});
+        else if (!HY || !(late_mask & 1u)) n_e = load4(t4x, 0, RingId<OALSFX_RV_MAIN>{}, base);
         if (!HY || !(late_mask & 2u)) n_a = load4(t4x, 1, RingId<OALSFX_RV_EARLY_AP>{}, base);
     };
     auto issue_taps_b = [&](unsigned t4x, int base) {
+        if (AW) {
+            const unsigned tile4 = t4x - 4u * static_cast<unsigned>(lane);
+            n_el = load4w(tile4, 2, RingId<OALSFX_RV_EARLY_LINE>{});
+            n_lt = load4w(tile4, 3, RingId<OALSFX_RV_MAIN>{});
+            n_ll = load4w(tile4, 5, RingId<OALSFX_RV_LATE_LINE>{});
+            return;
+        }
         if (!HY || !(late_mask & 4u)) n_el = load4(t4x, 2, RingId<OALSFX_RV_EARLY_LINE>{}, base);
         if (!HY || !(late_mask & 8u)) n_lt = load4(t4x, 3, RingId<OALSFX_RV_MAIN>{}, base);
         if (!HY || !(late_mask & 32u)) n_ll = load4(MD ? t4x - 4u * static_cast<unsigned>(md_next) : t4x, 5, RingId<OALSFX_RV_LATE_LINE>{}, base);
@@ -774,6 +826,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if (go) {
         if (FP && !(flags & kFiltered)) { n_in0 = early_in0; n_in1 = early_in1; }
         else issue_input(lane);
+        if (AW) w_e = load4w((static_cast<unsigned>(offset) << 2) - 256u, 0, RingId<OALSFX_RV_MAIN>{}); // the window before the first tile's
         issue_taps_a(static_cast<unsigned>(offset + lane) << 2, tapbase(0));
     }
     stamp(); // [3] first requests issued
@@ -820,6 +873,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         float oa0 = 0.0F, oa1 = 0.0F;
         float outva[MC ? 8 : 1] = {}; // the dry mix (or the running mix of the slots before) of tile ta
         v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
+        if (AW && go && has_b) {
+            // the long rings' samples of tile tb: each lane's from the window requested for the tile or from the one before it
+            const unsigned tile4 = static_cast<unsigned>(offset + (tb << 6)) << 2;
+            p_e = rotate4(w_e, n_e, tile4, 0); p_el = rotate4(w_el, n_el, tile4, 2); p_lt = rotate4(w_lt, n_lt, tile4, 3); p_ll = rotate4(w_ll, n_ll, tile4, 5);
+            w_e = n_e; w_el = n_el; w_lt = n_lt; w_ll = n_ll;
+        }
         const int xg = eax ? 0 : 2; // where the shelves left their output
         // XF: is the late half's tile one in which the taps are cross-faded?  mu: how far, per sample; q_*: the taps being faded in
         const bool xf_faded = XF && xf_active && has_b && fc0 + (tb << 6) < OALSFX_RV_FADE_SAMPLES;
@@ -1100,6 +1159,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
         if (go && has_a) {
             // (all of a tile's requests at the top of S1, or the late all-pass group here instead of in S3: measured, no faster)
+            if (AW && ta == 0) {
+                // the windows before the first tile's
+                const unsigned before4 = (static_cast<unsigned>(offset) << 2) - 256u;
+                w_el = load4w(before4, 2, RingId<OALSFX_RV_EARLY_LINE>{}); w_lt = load4w(before4, 3, RingId<OALSFX_RV_MAIN>{}); w_ll = load4w(before4, 5, RingId<OALSFX_RV_LATE_LINE>{});
+            }
             issue_taps_b(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta)); // on their way while the chain phases run
             __builtin_amdgcn_sched_barrier(0);
         }
