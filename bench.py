@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 FRAMES = 256
 CHANNELS = 2
 BYTES_PER_FRAME = 208          # 16 B I/O + 24 fp32 delay-line reads + 24 fp32 delay-line writes
-TIMED_EVERY = int(os.environ.get("OALSFX_TIMED_EVERY", "8"))
+TIMED_EVERY = int(os.environ.get("OALSFX_TIMED_EVERY", "8"))   # (the config5 leg: every 8th step carries events)
+KERNEL_STATS_STEPS = 32        # launches timed one by one for the `kernels` object, outside the timed region
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 VALU_SIMDS = 1024              # 256 CUs x 4 SIMDs
 VALU_CLOCK_GHZ = 2.4
@@ -349,13 +350,18 @@ def main():
             # by a synchronising call) they are listed for the steady-state builds: let that happen inside the warm-up, however short
             batch.synchronize()
 
-    # every 8th step carries the events: a timed launch costs a few microseconds of dispatch overhead, which would otherwise
-    # be part of `value`
+    # the timed region carries no events: an event pair around a launch costs that step about 10 us of dispatch overhead (the roofline
+    # region and the short region below have them instead)
     batch.synchronize()
-    batch.kernel_timing(0 if args.no_kernel_timing else TIMED_EVERY)
+    batch.kernel_timing(0)
     elapsed = timed_region(batch, src, dst, n_in, args.warmup, args.steps, sharding, backend)
 
-    # per effect type: launches and summed HIP-event duration of its kernel(s) over the timed region
+    # per effect type: launches and summed HIP-event duration of its kernel(s), over a short region of its own behind the timed one
+    if not args.no_kernel_timing:
+        batch.kernel_timing(1)
+        for k in range(KERNEL_STATS_STEPS):
+            batch.mix_device(FRAMES, src[(args.warmup + args.steps + k) % n_in].data_ptr(), dst.data_ptr())
+        batch.synchronize()
     kernels = {}
     timed = {"wave_effects (all ring-light types of a slot, one launch)": desc.CHORUS, "reverb + eax_reverb steady-state": desc.EAX_REVERB,
              "reverb + eax_reverb general": desc.REVERB + 16,
@@ -375,7 +381,7 @@ def main():
     plan = batch.plan(workloads.effect_count(workload) - 1)
     if workload == "config2" and not args.no_kernel_timing:
         # the headline: the dominant kernel alone, on its own fixed region
-        roofline = roofline_region(batch, src, dst, n_in, args.warmup + args.steps, bytes_per_step)
+        roofline = roofline_region(batch, src, dst, n_in, args.warmup + args.steps + KERNEL_STATS_STEPS, bytes_per_step)
     else:
         # several kernels share a step, some of them side by side on forked streams: the step's algorithmic bytes
         # against the step time itself

@@ -330,9 +330,11 @@ struct SteadyShared {
                                       : (Lds<CH>::kFloats > kSteadyFloats ? Lds<CH>::kFloats : kSteadyFloats);
     alignas(16) float lds_all[NW][kFloats];
     float chain_all[NW][4][coop::SIZE]; // [wave][line]: filter histories and feedback coefficients
-    unsigned tapn_all[FP ? 1 : NW][24]; // XF: [wave][group * 4 + line]: the taps being faded in, as byte distances like ut::TAP4
-    alignas(16) float sf_rows[SF ? NW : 1][SF ? 4 * CH : 1][kRow]; // SF: [wave][stage * 2 * CH + send * CH + channel]
-    float sf_misc[SF ? NW : 1][sfm::SIZE];
+    // (the workgroup's LDS decides how many fit a CU -- four at 40 KiB each --, and the multichannel builds sit just under that: what a
+    // build does not use is kept to a stub)
+    unsigned tapn_all[(FP || MC) ? 1 : NW][24]; // XF: [wave][group * 4 + line]: the taps being faded in, as byte distances like ut::TAP4
+    alignas(16) float sf_rows[SF ? NW : 1][SF ? 4 * CH : 1][SF ? kRow : 4]; // SF: [wave][stage * 2 * CH + send * CH + channel]
+    float sf_misc[SF ? NW : 1][SF ? sfm::SIZE : 4];
     int sf_all[NW]; // SF: which instances of the group filter their sends in here
     int go_all[NW];
     int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
@@ -354,7 +356,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     static_assert(!SF || (FP && !MD && !ST && NW == 4), "send filters inside: the FP plain and HY builds");
     constexpr int kSfRows = 2 * CH; // SF: rows per stage = sends (direct, this slot's auxiliary) x input channels
     // XF: dword offset (from the table) of the taps being faded in: a second tap table with ut::TAP4's layout, in the workgroup's own array
-    const int kTapN = static_cast<int>(reinterpret_cast<float*>(&sh.tapn_all[FP ? 0 : wib_of(threadIdx.x)][0]) - (sh.lds_all[wib_of(threadIdx.x)] + kSteadyGroups * 4 * kRow));
+    const int kTapN = static_cast<int>(reinterpret_cast<float*>(&sh.tapn_all[(FP || CH > 2) ? 0 : wib_of(threadIdx.x)][0]) - (sh.lds_all[wib_of(threadIdx.x)] + kSteadyGroups * 4 * kRow));
     // TL: measurement build, every 64th workgroup stamps the shader clock at each phase boundary (up to 96 stamps per wave)
     int ts_i = 0;
     auto stamp = [&]() {

@@ -38,3 +38,15 @@ if [ -f ab/liboalsfx_hip_r01.so ]; then
   bash scripts/ab_type_libs.sh ab/liboalsfx_hip_r01.so oalsfxpp_amd/csrc/liboalsfx_hip.so 2>/dev/null | grep -E "==|median|b / a" > $O/ab_round1_vs_round2_ring_light_types.txt || true
 fi
 echo "micro-benchmarks done" >> $O/progress.txt
+# round 3 additions
+python3 scripts/kinds_presets_bench.py 2>/dev/null | grep step > $O/kinds_presets.txt || true
+python3 scripts/low_rate_bench.py 2>/dev/null | grep step > $O/low_rates.txt || true
+OALSFX_DEBUG_FLAGS=0x200 python3 scripts/send_filter_bench.py 2>/dev/null | grep -v "^$" > $O/send_filters_with_the_pre_pass_kernel.txt || true
+OALSFX_DEBUG_FLAGS=0x40000000 python3 scripts/update_storm_bench.py 2>/dev/null | grep updates > $O/update_storm_without_the_cross_fading_build.txt || true
+python3 scripts/overlap_probe.py 2>/dev/null | grep step > $O/overlap_probe.txt || true
+bash scripts/storm_kernels.sh $N/storm4 4 > /dev/null 2>&1 || true
+bash scripts/gap_trace.sh $N/gap > /dev/null 2>&1 || true
+bash scripts/pmc_configs.sh $N/pmc_configs > /dev/null 2>&1 || true
+bash scripts/pmc_types.sh > /dev/null 2>&1 && cp $R/gpurun_out/pmc_types/per_type_counters.txt $O/per_effect_type_counters.txt || true
+bash scripts/pmc_mem.sh $N/pmc_mem > /dev/null 2>&1 || true
+echo "round 3 additions done" >> $O/progress.txt

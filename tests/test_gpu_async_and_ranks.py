@@ -132,7 +132,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
                     tmp.synchronize()
                     src[k][r * 64 * 512:(r + 1) * 64 * 512] = part
         torch.cuda.synchronize()
-        steps = 8 + 8 + 64 + 128   # warm-up, timed region, the fixed roofline region (bench.ROOFLINE_WARMUP + ROOFLINE_LAUNCHES)
+        steps = 8 + 8 + 32 + 64 + 128   # warm-up, timed region, kernel statistics (bench.KERNEL_STATS_STEPS), the fixed roofline region (bench.ROOFLINE_WARMUP + ROOFLINE_LAUNCHES)
         for k in range(steps):
             b.mix_device(256, src[k % 8].data_ptr(), dst.data_ptr())
         b.synchronize()
