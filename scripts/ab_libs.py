@@ -2,7 +2,7 @@
 """Same box, same process: two builds of liboalsfx_hip.so timed alternately on the headline workload (one batch per build, resident
 together), many rounds; per round the average HIP-event duration of the steady-state reverb launch, then the median over rounds.
 
-    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets | type:<NAME of a ring-light type, e.g. type:CHORUS>] [frames per call]
+    python scripts/ab_libs.py <a.so> <b.so> [instances] [workload: eax | presets | type:<NAME of a ring-light type, e.g. type:CHORUS>] [frames per call] [--wall]
 
 Raw ctypes on both libraries (two builds cannot share the Python mirror's single handle)."""
 import ctypes as C
@@ -15,6 +15,8 @@ import torch  # noqa: E402,F401  (first: one HIP runtime for everything)
 
 from oalsfxpp_amd import desc  # noqa: E402
 
+WALL = "--wall" in sys.argv   # time whole steps (host clock, k calls then one synchronisation) instead of the kernel's event pairs
+sys.argv = [a for a in sys.argv if a != "--wall"]
 paths = [os.path.abspath(p) for p in sys.argv[1:3]]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 workload = sys.argv[4] if len(sys.argv) > 4 else "eax"
@@ -66,6 +68,14 @@ class Lib:
         assert self.so.oalsfx_batch_synchronize(self.h)
 
     def timed(self, k):
+        if WALL:
+            # whole steps on the host's clock (what bench.py's `value` is made of): k calls, one synchronisation
+            import time
+            self.sync()
+            t0 = time.perf_counter()
+            self.run(k)
+            self.sync()
+            return (time.perf_counter() - t0) / k * 1e6
         self.so.oalsfx_batch_kernel_timing(self.h, 1)
         self.run(k)
         self.sync()
@@ -91,7 +101,8 @@ for rnd in range(12):
         rounds[order[k]].append(t)
         per_batch[k].append(t)
 pair = C.c_double(0.0)
-libs[1].so.oalsfx_batch_event_overhead(libs[1].h, 200, C.byref(pair))
+if not WALL:
+    libs[1].so.oalsfx_batch_event_overhead(libs[1].h, 200, C.byref(pair))
 for which in (0, 1):
     v = sorted(rounds[which])
     print(f"{os.path.basename(paths[which]):36s} median of {len(v)} rounds x 64 launches (two batches): {v[len(v) // 2] - pair.value:6.2f} us   "
