@@ -277,6 +277,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiment: no HIP events around the launches (roofline fields then use the step time)")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
+    ap.add_argument("--no-chain", action="store_true", help="consecutive calls in plain stream order (no overlap of a launch's tail with the "
+                    "next one's head): the configuration whose rocprofv3 kernel durations are those of the kernel alone")
     ap.add_argument("--preset", type=int, default=-1, help="experiment: every instance uses EFX preset N")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
                     help="BASELINE.json configs[1] (default, the headline metric), configs[2] (4-slot chain), configs[3] (11 effect types, "
@@ -292,6 +294,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (before torch or HIP are touched in this process)
         sys.exit(spawn_ranks(args.gpus))
+
+    if args.no_chain:
+        # (read once by the library, at its first call: before it is loaded)
+        os.environ["OALSFX_DEBUG_FLAGS"] = hex(int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0) | 0x400)
 
     import torch
     import torch.distributed as dist
@@ -354,7 +360,9 @@ def main():
     # region and the short region below have them instead)
     batch.synchronize()
     batch.kernel_timing(0)
+    chained_before = batch.chained_calls
     elapsed = timed_region(batch, src, dst, n_in, args.warmup, args.steps, sharding, backend)
+    chained = batch.chained_calls - chained_before
 
     # per effect type: launches and summed HIP-event duration of its kernel(s), over a short region of its own behind the timed one
     if not args.no_kernel_timing:
@@ -437,6 +445,14 @@ def main():
         "roofline": roofline,
         "kernels": kernels,
     }
+    # Consecutive calls of the timed region overlap on the device where the step is one steady-state launch (chained launches):
+    # the launches of the roofline region carry events and run alone, one after the other -- `frac` is the kernel by itself; what the
+    # chip moves with two launches in flight is the step's bytes over the step time
+    step_gbs = bytes_per_step / (elapsed / args.steps) / 1e9
+    result["roofline"]["chained_launches"] = {
+        "calls_chained_in_timed_region": chained, "of": args.steps, "step_us": round(elapsed / args.steps * 1e6, 2),
+        "achieved_over_step": round(step_gbs, 1), "frac_over_step": round(step_gbs / HBM_PEAK_GBS, 4),
+        "note": "algorithmic bytes of a step / step time of the CLI-timed region (launch gaps included); --no-chain runs the region in plain stream order"}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and workload == "config2" and n == 4096 and not args.no_kernel_timing:
         with open(traffic_file) as f:

@@ -76,9 +76,16 @@ int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* 
  * out, in microseconds (a measurement aid: bench.py's host_io object says with it where a slow box loses the time). */
 int oalsfx_batch_mix_timed(oalsfx_batch* b, int frames, const float* src_host, float* dst_host, double legs_us[3]);
 /* Same with buffers already resident in device memory; launches on `hip_stream` (a hipStream_t, or
- * NULL for the batch's own stream) and returns without synchronising. */
+ * NULL for the batch's own stream) and returns without synchronising.
+ * With hip_stream NULL the call is complete when oalsfx_batch_synchronize (or any other call on the batch that waits or reads back)
+ * returns; consecutive such calls may overlap on the device where the instances allow it (a step that is one steady-state reverb
+ * launch: each instance of the later call starts when the earlier call is through with that instance), which takes the launch gap
+ * between dependent kernels out of a streaming loop.  A caller that wants the launches in the order of a stream it can queue its
+ * own work on passes that stream, or asks for the batch's with oalsfx_batch_stream, which switches the overlap off. */
 int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream);
 int oalsfx_batch_synchronize(oalsfx_batch* b);
+/* How many oalsfx_batch_mix_device calls overlapped with their neighbours that way so far (tests, benchmark records). */
+long long oalsfx_batch_chained_calls(const oalsfx_batch* b);
 /* Api::mix for a caller that streams buffer after buffer from host memory (what the reference's only entry point is used for,
  * src/oalsfxpp.cpp:3785-3829, src/oalsfxpp_test.cpp:891): returns as soon as the call is queued.  The copy in of call k + 1, the
  * kernels of call k and the copy out of call k - 1 overlap on three streams, ordered by events.  `src_host` and `dst_host` must stay
@@ -93,7 +100,8 @@ int oalsfx_batch_wait(oalsfx_batch* b);
 /* Page-locked host memory for the two calls above (hipHostMalloc / hipHostFree), so that a caller need not link HIP itself. */
 void* oalsfx_pinned_alloc(unsigned long long bytes);
 void oalsfx_pinned_free(void* p);
-/* The batch's own HIP stream (a hipStream_t) so callers can bracket launches with their own events. */
+/* The batch's own HIP stream (a hipStream_t) so callers can bracket launches with their own events.  From this call on every launch of
+ * oalsfx_batch_mix_device(..., NULL) is in the order of that stream (no overlap of consecutive calls). */
 void* oalsfx_batch_stream(oalsfx_batch* b);
 
 /* ---- state read-back for tests and checkpoints (the reference keeps this in private members of

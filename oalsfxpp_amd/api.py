@@ -190,6 +190,11 @@ class Batch:
         return c.value, k.value, a.value, w.value
 
     @property
+    def chained_calls(self):
+        """mix_device calls (own stream) that overlapped with their neighbours on the device so far."""
+        return self._lib.oalsfx_batch_chained_calls(self._h)
+
+    @property
     def last_reverb_kernel(self):
         return (self._lib.oalsfx_batch_last_reverb_kernel(self._h) or b"").decode()
 

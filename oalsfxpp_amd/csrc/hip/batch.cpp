@@ -99,7 +99,7 @@ struct oalsfx_batch {
 
     // device
     oalsfx_slot_params* d_params = nullptr;
-    oalsfx_slot_state* d_state = nullptr;
+    oalsfx_hip::SlotStateLines* d_state = nullptr;
     oalsfx_source_params* d_source = nullptr;
     float** d_rings = nullptr;
     oalsfx_source_state* d_source_state = nullptr; // [n] histories of the send filters
@@ -164,6 +164,23 @@ struct oalsfx_batch {
     const char* last_steady_kernel = "";          // symbol of the last steady-state reverb launch
 
     hipStream_t stream = nullptr;
+    // Chained launches: consecutive calls on the batch's own stream whose whole step is one steady-state reverb launch take turns on two
+    // streams with nothing but a word per instance ordering them (KernelCtx::turn), so that the tail of one launch overlaps with the head
+    // of the next (the ~6 us between dependent launches of one stream).  Off once the caller has asked for the stream handle: work
+    // queued there by the caller expects the launches in stream order.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_chain = nullptr;
+    hipEvent_t ev_chain_start = nullptr;          // recorded in front of a run's first launch: the second (other stream) starts no earlier
+    unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups that first launches of runs started (k_chain_gate)
+    uint32_t turn_counter = 0;                    // the number the last chained launch set
+    uint32_t started_total = 0;                   // what that count comes to once the first launch of the last run has started as a whole
+    int chain_len = 0;                            // launches in the current run
+    int resident_groups = 0;                      // workgroups of a steady-state reverb launch the device holds at once (4 per CU)
+    bool uncached = false;                        // what launches hand on lives in uncached memory: calls can be chained launches
+    bool chain_open = false;                      // the last call was a chained launch (its kernel may still run, on either stream)
+    bool chain_on_second = false;                 // ... on stream2
+    bool stream_handed_out = false;
+    long long chained_calls = 0;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
     // is populated they run side by side on these streams, forked from and joined to the launch stream with events
     hipStream_t side_stream[kSideStreams] = {};
@@ -334,6 +351,82 @@ void advance_settling(oalsfx_batch* b, int frames)
 // leaves the memory zero-filled), stops once it holds enough of the fastest kind and has seen a clearly slower one (or after
 // 96 candidates -- four times the chunks wanted if that is more --, or half the free memory), keeps the fastest and frees the rest.  A few hundred milliseconds, once per
 // batch.  OALSFX_DEBUG_FLAGS 0x4000000 switches the search off.
+// What one launch hands to the next -- delay lines, effect state, hot records, send-filter histories, the turn words of chained launches
+// -- lives, for a batch whose calls can be chained launches (chain_capable), in memory the L2s do not cache (hipDeviceMallocUncached): a
+// wavefront's acknowledged stores are then in memory for every XCD to see, which is what lets consecutive calls overlap without a
+// write-back of the L2 in between.  The kernels stream through this memory anyway: measured neutral on every workload
+// (profiles/r03k_chained_launches/uncached_memory.txt: headline 42.9 / 43.1 / 42.4 us for default / fine-grained / uncached, the other
+// BASELINE configurations within their noise).  Fine-grained memory is not enough: plain loads and stores of it are as stale across XCDs
+// as those of ordinary memory (tests/test_gpu_chained.py fails on it).
+// OALSFX_RING_MEMORY=default | finegrained | uncached forces one kind for every batch (comparisons; no chained launches unless uncached).
+//
+// Uncached memory is never given back to the runtime: freed and handed out again as ordinary memory it misbehaved -- whole output
+// buffers of a later batch read back as zeros (scripts/uncached_free_hazard.py; gone when the blocks are kept) -- so a block a batch is done with
+// waits in a process-wide pool for the next batch that asks for its size on its device.
+class UncachedPool {
+public:
+    hipError_t take(int device, size_t bytes, void** p)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            auto it = free_.find({device, bytes});
+            if (it != free_.end()) {
+                *p = it->second;
+                free_.erase(it);
+                live_[*p] = {device, bytes};
+                return hipSuccess;
+            }
+        }
+        const hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lock(mutex_);
+            live_[*p] = {device, bytes};
+        }
+        return e;
+    }
+    bool give_back(void* p) // false: not one of ours
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        auto it = live_.find(p);
+        if (it == live_.end()) return false;
+        free_.insert({it->second, p});
+        live_.erase(it);
+        return true;
+    }
+    size_t bytes_waiting()
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        size_t total = 0;
+        for (const auto& kv : free_) total += kv.first.second;
+        return total;
+    }
+
+private:
+    std::mutex mutex_;
+    std::multimap<std::pair<int, size_t>, void*> free_;
+    std::map<void*, std::pair<int, size_t>> live_;
+};
+
+UncachedPool& uncached_pool()
+{
+    static UncachedPool* pool = new UncachedPool; // (never destroyed: batches may outlive static destruction order)
+    return *pool;
+}
+
+hipError_t handed_on_malloc(const oalsfx_batch* b, void** p, size_t bytes)
+{
+    const char* kind = std::getenv("OALSFX_RING_MEMORY");
+    if (kind && std::strcmp(kind, "finegrained") == 0) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (kind && std::strcmp(kind, "default") == 0) return hipMalloc(p, bytes);
+    if (b->uncached || (kind && std::strcmp(kind, "uncached") == 0)) return uncached_pool().take(b->device, bytes, p);
+    return hipMalloc(p, bytes);
+}
+
+void handed_on_free(void* p)
+{
+    if (p && !uncached_pool().give_back(p)) (void)hipFree(p);
+}
+
 bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_floats, std::vector<float*>& out)
 {
     if (chunks <= 0) return true;
@@ -359,11 +452,11 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
     if (!search) {
         for (int k = 0; k < chunks; ++k) {
             void* p = nullptr;
-            bool ok = b->hip_ok(hipMalloc(&p, bytes), "hipMalloc(rings)");
+            bool ok = b->hip_ok(handed_on_malloc(b, &p, bytes), "hipMalloc(rings)");
             if (ok) cands.push_back({p, 0.0});
             ok = ok && b->hip_ok(hipMemsetAsync(p, 0, bytes, b->stream), "hipMemsetAsync(rings)");
             if (!ok) {
-                for (auto& c : cands) (void)hipFree(c.p);
+                for (auto& c : cands) handed_on_free(c.p);
                 return false;
             }
         }
@@ -375,7 +468,7 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
         bool ok = true;
         while (cands.size() < max_tries) {
             void* c = nullptr;
-            if (hipMalloc(&c, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (handed_on_malloc(b, &c, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
             cands.push_back({c, 1e30});
             if (!(ok = b->hip_ok(hipMemsetAsync(c, 0, bytes, b->stream), "hipMemsetAsync(rings)"))) break;
             for (int r = 0; r < 2; ++r) oalsfx_hip::launch_ring_probe(static_cast<float*>(c), count, slab_floats, 256u * r, waves_per_slab, b->stream);
@@ -396,10 +489,10 @@ bool place_ring_chunks(oalsfx_batch* b, int chunks, int count, size_t slab_float
         hipEventDestroy(e0); hipEventDestroy(e1);
         std::stable_sort(cands.begin(), cands.end(), [](const Candidate& x, const Candidate& y) { return x.us < y.us; });
         if (!ok || static_cast<int>(cands.size()) < chunks) {
-            for (auto& c : cands) (void)hipFree(c.p);
+            for (auto& c : cands) handed_on_free(c.p);
             return ok ? b->fail("hipMalloc(rings) failed") : false;
         }
-        for (size_t k = chunks; k < cands.size(); ++k) (void)hipFree(cands[k].p);
+        for (size_t k = chunks; k < cands.size(); ++k) handed_on_free(cands[k].p);
         b->placement_worst_us = std::max(b->placement_worst_us, cands.back().us);
         cands.resize(chunks);
         b->placement_best_us = cands.front().us;
@@ -653,7 +746,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
     const size_t o_pi = off; off += padded(n_p * sizeof(int));
     const size_t o_pr = off; off += padded(n_p * sizeof(oalsfx_slot_params));
     const size_t o_si = off; off += padded(n_s * sizeof(int));
-    const size_t o_sr = off; off += padded(n_s * sizeof(oalsfx_slot_state));
+    const size_t o_sr = off; off += padded(n_s * sizeof(oalsfx_hip::SlotStateLines)); // (records in whole lines, as they lie in device memory)
     const size_t o_ci = off; off += padded(n_src * sizeof(int));
     const size_t o_cr = off; off += padded(n_src * sizeof(oalsfx_source_params));
     const size_t o_ti = off; off += padded(n_t * sizeof(int));
@@ -666,7 +759,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         if (n_p) std::memcpy(st->host + o_pi, up_params.data(), n_p * sizeof(int));
         for (size_t k = 0; k < n_p; ++k) std::memcpy(st->host + o_pr + k * sizeof(oalsfx_slot_params), &b->h_params[up_params[k]], sizeof(oalsfx_slot_params));
         if (n_s) std::memcpy(st->host + o_si, up_state.data(), n_s * sizeof(int));
-        for (size_t k = 0; k < n_s; ++k) std::memcpy(st->host + o_sr + k * sizeof(oalsfx_slot_state), &b->h_state_init[up_state[k]], sizeof(oalsfx_slot_state));
+        for (size_t k = 0; k < n_s; ++k) std::memcpy(st->host + o_sr + k * sizeof(oalsfx_hip::SlotStateLines), &b->h_state_init[up_state[k]], sizeof(oalsfx_slot_state));
         if (n_src) std::memcpy(st->host + o_ci, up_source.data(), n_src * sizeof(int));
         for (size_t k = 0; k < n_src; ++k) std::memcpy(st->host + o_cr + k * sizeof(oalsfx_source_params), &b->h_source[up_source[k]], sizeof(oalsfx_source_params));
         if (n_t) std::memcpy(st->host + o_ti, up_touched.data(), n_t * sizeof(int));
@@ -685,7 +778,7 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         auto ints = [&](size_t o) { return reinterpret_cast<const int*>(from + o); };
         oalsfx_hip::UploadJobs jobs{};
         jobs.scatter[0] = {reinterpret_cast<unsigned*>(b->d_params), words(o_pr), ints(o_pi), static_cast<int>(sizeof(oalsfx_slot_params) / 4), static_cast<int>(n_p)};
-        jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_slot_state) / 4), static_cast<int>(n_s)};
+        jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_hip::SlotStateLines) / 4), static_cast<int>(n_s)};
         jobs.scatter[2] = {reinterpret_cast<unsigned*>(b->d_source), words(o_cr), ints(o_ci), static_cast<int>(sizeof(oalsfx_source_params) / 4), static_cast<int>(n_src)};
         jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ti), 1, static_cast<int>(n_t)};
         jobs.copy[0] = {reinterpret_cast<unsigned*>(b->d_rings), words(o_rt), rings_changed ? total * (sizeof(float*) / 4) : 0, 0};
@@ -999,9 +1092,43 @@ SlotPlan plan_slot(const oalsfx_batch* b, const KernelCtx& ctx, int s, int n, bo
     return p;
 }
 
-bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream)
+// Ends a run of chained launches: everything queued on the batch's stream from here on comes behind the launch that may still run on
+// the second stream.
+bool chain_join(oalsfx_batch* b)
+{
+    if (!b->chain_open) return true;
+    b->chain_open = false;
+    if (!b->chain_on_second) return true;
+    return b->hip_ok(hipEventRecord(b->ev_chain, b->stream2), "hipEventRecord") && b->hip_ok(hipStreamWaitEvent(b->stream, b->ev_chain, 0), "hipStreamWaitEvent");
+}
+
+// Can this call be a chained launch?  The batch's own stream, nobody holding its handle, nothing to upload, no per-launch events, one
+// chunk of whole tiles, and a step that is exactly one steady-state launch of at most as many workgroups as the chip holds at once
+// (then the launch before is resident as a whole before this one gets a workgroup, and no wait on a turn word can starve).
+bool chain_eligible(oalsfx_batch* b, int frames, hipStream_t stream)
+{
+    if (stream != b->stream || b->stream_handed_out || (debug_flags() & (0x400 | 8)) || b->timing_every > 0 || b->d_timeline) return false;
+    if (!b->uncached) return false;
+    for (const auto& kv : b->pools)
+        if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
+    if (!b->dirty_list.empty() || b->lists_dirty || b->exact_wanted) return false;
+    if (b->slots != 1 || b->channels > 2 || b->n_filtered > 0 || frames > OALSFX_MAX_CHUNK || (frames & 63) != 0) return false;
+    const int steady = b->fast_count[0] + b->slow_count[0];
+    if (steady != b->n || b->general_count[0] != 0) return false;
+    // (k_reverb_steady_kinds: a kind's incomplete workgroup goes to the next kind, steady_kind_counts: the grid is exactly this long)
+    return (b->n + 3) / 4 <= b->resident_groups;
+}
+
+bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream, bool may_chain = false)
 {
     poll_exact(b);
+    const bool chained = may_chain && chain_eligible(b, frames, stream);
+    if (!chained && !chain_join(b)) return false;
+    if (chained) {
+        // take turns on the two streams; the first of a run stays on the batch's stream, behind whatever was queued there before
+        b->chain_on_second = b->chain_open && !b->chain_on_second;
+        stream = b->chain_on_second ? b->stream2 : b->stream;
+    }
     if (!sync_params(b, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
     b->timing = b->timing_every > 0 && (b->mix_calls++ % b->timing_every) == 0;
@@ -1030,6 +1157,27 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.fault = b->d_fault;
     ctx.list_first = -1;
     ctx.no_follow_up = 0;
+    if (chained) {
+        ctx.turn = b->d_turn;
+        ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
+        if (++b->turn_counter == 0u) b->turn_counter = 1u;
+        ctx.turn_set = b->turn_counter;
+        unsigned* started = b->d_turn + static_cast<size_t>(b->n) * b->slots;
+        if (!b->chain_open) {
+            // the first of a run: its workgroups count themselves in as they start
+            if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
+            ctx.turn_started = started;
+            b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
+            b->chain_len = 1;
+        } else if (b->chain_len++ == 1) {
+            // the second (the first on the other stream, and the first whose workgroups wait): not before the first could start, and
+            // then not before all but a few of the first's workgroups are on the chip (k_chain_gate)
+            if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
+            oalsfx_hip::launch_chain_gate(started, b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1)), b->d_fault, stream);
+        }
+        b->chain_open = true;
+        b->chained_calls += 1;
+    }
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
@@ -1154,8 +1302,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         b->exact_wanted = false;
         b->exact_gen = b->upload_gen;
     }
-    b->last_launch_stream = stream;
-    if (stream != b->stream && !b->hip_ok(hipEventRecord(b->ev_mixed, stream), "hipEventRecord")) return false;
+    b->last_launch_stream = chained ? b->stream : stream;
+    if (!chained && stream != b->stream && !b->hip_ok(hipEventRecord(b->ev_mixed, stream), "hipEventRecord")) return false;
     return b->hip_ok(hipGetLastError(), "kernel launch");
 }
 
@@ -1219,6 +1367,19 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     mark_touched(b, 0, n_instances);
 
     bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
+    ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking), "hipStreamCreate");
+    {
+        // every steady-state build is held to four workgroups per CU (registers, LDS: tests/test_kernel_resources.py)
+        int cus = 0;
+        ok = ok && b->hip_ok(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device), "hipDeviceGetAttribute");
+        b->resident_groups = 4 * cus;
+        // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
+        const char* kind = std::getenv("OALSFX_RING_MEMORY");
+        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances + 3) / 4 <= b->resident_groups && !(debug_flags() & 0x400) &&
+                      (!kind || std::strcmp(kind, "uncached") == 0);
+    }
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain, hipEventDisableTiming), "hipEventCreate");
+    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
     for (int k = 0; k < kSideStreams; ++k) {
         ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->side_stream[k], hipStreamNonBlocking), "hipStreamCreate");
         ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming), "hipEventCreate");
@@ -1227,25 +1388,27 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_uploaded, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_mixed, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_params), total * sizeof(oalsfx_slot_params)), "hipMalloc(params)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_slot_state)), "hipMalloc(state)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_state), total * sizeof(oalsfx_hip::SlotStateLines)), "hipMalloc(state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_hot), total * oalsfx_hip::hot::SIZE * sizeof(unsigned)), "hipMalloc(hot records)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_hot), total * oalsfx_hip::hot::SIZE * sizeof(unsigned)), "hipMalloc(hot records)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_hot, 0, total * oalsfx_hip::hot::SIZE * sizeof(unsigned), b->stream), "hipMemsetAsync(hot records)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_inst_epoch), n_instances * sizeof(unsigned)), "hipMalloc(epochs)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_inst_epoch, 0, n_instances * sizeof(unsigned), b->stream), "hipMemsetAsync(epochs)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_turn), (total + 16) * sizeof(unsigned)), "hipMalloc(turns)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_turn, 0, (total + 16) * sizeof(unsigned), b->stream), "hipMemsetAsync(turns)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_exact, 0, total * sizeof(unsigned), b->stream), "hipMemsetAsync(exact)");
     ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_exact), total * sizeof(unsigned)), "hipHostMalloc(exact)");
     ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_fault), sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(fault)");
     if (ok) *b->h_fault = 0;
     ok = ok && b->hip_ok(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_fault), b->h_fault, 0), "hipHostGetDevicePointer");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_exact, hipEventDisableTiming), "hipEventCreate");
-    ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_slot_state), b->stream), "hipMemsetAsync(state)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_hip::SlotStateLines), b->stream), "hipMemsetAsync(state)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_source_state, 0, n_instances * sizeof(oalsfx_source_state), b->stream), "hipMemsetAsync(source state)");
     if (ok && std::getenv("OALSFX_DEBUG_TIMELINE")) {
         ok = b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_timeline), kTimelineBytes), "hipMalloc(timeline)");
@@ -1263,6 +1426,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
 {
     if (!b) return;
     hipSetDevice(b->device);
+    if (b->stream2) hipStreamSynchronize(b->stream2);
     if (b->stream) hipStreamSynchronize(b->stream);
     for (int k = 0; k < kSideStreams; ++k)
         if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
@@ -1276,10 +1440,13 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     }
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (hipEvent_t e : b->event_pool) hipEventDestroy(e);
-    for (void* c : b->chunks) hipFree(c);
-    hipFree(b->d_params); hipFree(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); hipFree(b->d_source_state); hipFree(b->d_filtered);
+    for (void* c : b->chunks) handed_on_free(c);
+    hipFree(b->d_params); handed_on_free(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); handed_on_free(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
-    hipFree(b->d_hot); hipFree(b->d_inst_epoch); hipFree(b->d_exact);
+    handed_on_free(b->d_hot); hipFree(b->d_inst_epoch); handed_on_free(b->d_exact); handed_on_free(b->d_turn);
+    if (b->ev_chain) hipEventDestroy(b->ev_chain);
+    if (b->ev_chain_start) hipEventDestroy(b->ev_chain_start);
+    if (b->stream2) hipStreamDestroy(b->stream2);
     if (b->h2d_stream) hipStreamSynchronize(b->h2d_stream);
     if (b->d2h_stream) hipStreamSynchronize(b->d2h_stream);
     for (auto& ps : b->pipe) {
@@ -1409,7 +1576,8 @@ int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, f
     if (!src_dev) return b->fail(kErrNoSrc) ? 1 : 0;
     if (!dst_dev) return b->fail(kErrNoDst) ? 1 : 0;
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
-    return mix_device(b, frames, src_dev, dst_dev, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream) ? 1 : 0;
+    // (calls on the batch's own stream may overlap with their neighbours: chained launches)
+    return mix_device(b, frames, src_dev, dst_dev, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream, hip_stream == nullptr) ? 1 : 0;
 }
 
 namespace {
@@ -1423,7 +1591,7 @@ int mix_host(oalsfx_batch* b, int frames, const float* src_host, float* dst_host
     if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
     if (!src_host) return b->fail(kErrNoSrc) ? 1 : 0;
     if (!dst_host) return b->fail(kErrNoDst) ? 1 : 0;
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     const size_t floats = static_cast<size_t>(b->n) * frames * b->channels;
     if (floats > b->io_capacity) {
         hipFree(b->d_io_src); hipFree(b->d_io_dst);
@@ -1470,7 +1638,7 @@ int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, f
     if (frames < 0) return b->fail("Frame count is negative.") ? 1 : 0;
     if (!src_host) return b->fail(kErrNoSrc) ? 1 : 0;
     if (!dst_host) return b->fail(kErrNoDst) ? 1 : 0;
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     const size_t floats = static_cast<size_t>(b->n) * frames * b->channels;
     if (!b->h2d_stream) {
         if (!b->hip_ok(hipStreamCreateWithFlags(&b->h2d_stream, hipStreamNonBlocking), "hipStreamCreate")) return 0;
@@ -1532,7 +1700,7 @@ int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, f
 
 int oalsfx_batch_wait(oalsfx_batch* b)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     if (b->d2h_stream && !b->hip_ok(hipStreamSynchronize(b->d2h_stream), "hipStreamSynchronize")) return 0;
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
     for (auto& ps : b->pipe) ps.busy = false;
@@ -1553,24 +1721,30 @@ void oalsfx_pinned_free(void* p)
 
 int oalsfx_batch_synchronize(oalsfx_batch* b)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
     poll_exact(b);
     return check_fault(b) ? 1 : 0;
 }
 
-void* oalsfx_batch_stream(oalsfx_batch* b) { return b->stream; }
+void* oalsfx_batch_stream(oalsfx_batch* b)
+{
+    // whoever holds the handle may queue work that expects the launches in stream order: no more chained launches for this batch
+    b->stream_handed_out = true;
+    if (hipSetDevice(b->device) == hipSuccess) (void)chain_join(b);
+    return b->stream;
+}
 
 int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_params* params, oalsfx_slot_state* state)
 {
     if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return b->fail(kErrRange) ? 1 : 0;
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     if (!sync_params(b, nullptr)) return 0;
     const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
     if (params) *params = b->h_params[idx];
     if (state) {
         if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
-        if (!b->hip_ok(hipMemcpy(state, b->d_state + idx, sizeof(*state), hipMemcpyDeviceToHost), "hipMemcpy(state)")) return 0;
+        if (!b->hip_ok(hipMemcpy(state, static_cast<const oalsfx_slot_state*>(b->d_state + idx), sizeof(*state), hipMemcpyDeviceToHost), "hipMemcpy(state)")) return 0;
     }
     return 1;
 }
@@ -1578,7 +1752,7 @@ int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_
 int oalsfx_batch_read_ring(oalsfx_batch* b, int instance, int slot, float* out, int max_floats)
 {
     if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
-    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || !sync_params(b, nullptr)) return 0;
     const size_t idx = static_cast<size_t>(instance) * b->slots + slot;
     const int floats = static_cast<int>(b->ring_floats[idx]);
     if (out && floats) {
@@ -1592,7 +1766,7 @@ int oalsfx_batch_read_ring(oalsfx_batch* b, int instance, int slot, float* out, 
 int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params* params, oalsfx_source_state* state)
 {
     if (instance < 0 || instance >= b->n) return b->fail(kErrRange) ? 1 : 0;
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     if (!sync_params(b, nullptr)) return 0;
     if (params) *params = b->h_source[instance];
     if (state) {
@@ -1604,14 +1778,14 @@ int oalsfx_batch_read_source(oalsfx_batch* b, int instance, oalsfx_source_params
 
 int oalsfx_batch_fill_synthetic(oalsfx_batch* b, int frames, unsigned buffer_index, float* dst_dev, void* hip_stream)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     oalsfx_hip::launch_fill_synthetic(dst_dev, b->n, frames * b->channels, buffer_index, hip_stream ? static_cast<hipStream_t>(hip_stream) : b->stream);
     return b->hip_ok(hipGetLastError(), "fill_synthetic") ? 1 : 0;
 }
 
 int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     for (auto& t : b->timed) { b->event_pool.push_back(t.start); b->event_pool.push_back(t.stop); }
     b->timed.clear();
     b->timing_every = enable > 0 ? enable : 0;
@@ -1627,7 +1801,7 @@ int oalsfx_batch_kernel_timing(oalsfx_batch* b, int enable)
 
 int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launches, double* total_ms)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     int n = 0;
     double ms = 0.0;
     // the ring-light types share one launch per slot: asking for any of them reads that launch
@@ -1651,7 +1825,7 @@ int oalsfx_batch_kernel_timing_read(oalsfx_batch* b, int effect_type, int* launc
 
 int oalsfx_batch_kernel_timing_samples(oalsfx_batch* b, int effect_type, double* out_us, int max_samples)
 {
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return -1;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return -1;
     int key = (effect_type >= 0 && effect_type < OALSFX_REVERB) ? kTimedWaveEffects : effect_type;
     if (key == OALSFX_REVERB) key = OALSFX_EAX_REVERB;
     if (key == OALSFX_EAX_REVERB + kTimedGeneralOffset) key = OALSFX_REVERB + kTimedGeneralOffset;
@@ -1673,7 +1847,7 @@ int oalsfx_batch_kernel_timing_samples(oalsfx_batch* b, int effect_type, double*
 int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4])
 {
     if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
-    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     poll_exact(b);
     if (!sync_params(b, nullptr)) return 0;
     int light = 0;
@@ -1687,6 +1861,8 @@ int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4])
 
 const char* oalsfx_batch_last_reverb_kernel(const oalsfx_batch* b) { return b->last_steady_kernel; }
 
+long long oalsfx_batch_chained_calls(const oalsfx_batch* b) { return b->chained_calls; }
+
 int oalsfx_device_pci_bus_id(int device_id, char* out, int len)
 {
     if (!out || len < 16) return 0;
@@ -1695,7 +1871,7 @@ int oalsfx_device_pci_bus_id(int device_id, char* out, int len)
 
 int oalsfx_batch_event_overhead(oalsfx_batch* b, int repeats, double* avg_us)
 {
-    if (repeats <= 0 || !b->hip_ok(hipSetDevice(b->device), "hipSetDevice")) return 0;
+    if (repeats <= 0 || !b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     hipEvent_t e0 = b->take_event(), e1 = b->take_event();
     double total = 0.0;
     bool ok = true;
@@ -1745,7 +1921,7 @@ int oalsfx_debug_probe_pointer(void* slabs, int instances, int slab_floats, int 
 int oalsfx_debug_probe_rings(oalsfx_batch* b, int repeats, double* avg_us)
 {
     // the reverb's ring traffic without its arithmetic (k_stream_pattern) on the batch's own delay-line chunk: overwrites the delay lines
-    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr) || b->ring_chunks.empty() || repeats <= 0) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || !sync_params(b, nullptr) || b->ring_chunks.empty() || repeats <= 0) return 0;
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
     const auto& rc = b->ring_chunks.front();
     const size_t slab_floats = static_cast<size_t>(ring_floats_for(OALSFX_EAX_REVERB, b->rate));
@@ -1766,12 +1942,12 @@ int oalsfx_debug_probe_rings(oalsfx_batch* b, int repeats, double* avg_us)
 
 int oalsfx_debug_move_rings(oalsfx_batch* b, int keep_old)
 {
-    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || !sync_params(b, nullptr)) return 0;
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
     const size_t total = static_cast<size_t>(b->n) * b->slots;
     for (auto& rc : b->ring_chunks) {
         void* fresh = nullptr;
-        if (!b->hip_ok(hipMalloc(&fresh, rc.bytes), "hipMalloc(rings)")) return 0;
+        if (!b->hip_ok(handed_on_malloc(b, &fresh, rc.bytes), "hipMalloc(rings)")) return 0;
         if (!b->hip_ok(hipMemcpy(fresh, rc.base, rc.bytes, hipMemcpyDeviceToDevice), "hipMemcpy(rings)")) return 0;
         const ptrdiff_t delta = static_cast<char*>(fresh) - rc.base;
         auto inside = [&](float* p) { return reinterpret_cast<char*>(p) >= rc.base && reinterpret_cast<char*>(p) < rc.base + rc.bytes; };
@@ -1786,7 +1962,7 @@ int oalsfx_debug_move_rings(oalsfx_batch* b, int keep_old)
             // stays allocated (and counted in `chunks`) so that the next move lands somewhere else again
         } else {
             for (auto& c : b->chunks) if (c == rc.alloc) c = nullptr;
-            (void)hipFree(rc.alloc);
+            handed_on_free(rc.alloc);
         }
         b->chunks.push_back(fresh);
         rc.base = static_cast<char*>(fresh);
@@ -1798,7 +1974,7 @@ int oalsfx_debug_move_rings(oalsfx_batch* b, int keep_old)
 unsigned long long oalsfx_debug_ring_address(oalsfx_batch* b, int instance, int slot)
 {
     if (instance < 0 || instance >= b->n || slot < 0 || slot >= b->slots) return 0;
-    if (hipSetDevice(b->device) != hipSuccess || !sync_params(b, nullptr)) return 0;
+    if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || !sync_params(b, nullptr)) return 0;
     return reinterpret_cast<unsigned long long>(b->h_rings[static_cast<size_t>(instance) * b->slots + slot]);
 }
 

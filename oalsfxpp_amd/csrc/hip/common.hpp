@@ -13,10 +13,17 @@
 
 namespace oalsfx_hip {
 
+// A slot's state in device memory: the ABI's record in 128-byte lines of its own.  No cache line holds parts of two instances' records
+// (hot records: 1 KiB each; send-filter histories: 1280 bytes each; delay lines: slabs of whole lines), which is what lets an instance
+// change hands between two launches that run at the same time with no cache invalidated in between (chained launches, reverb.hip).
+struct alignas(128) SlotStateLines : oalsfx_slot_state {};
+static_assert(sizeof(SlotStateLines) % 128 == 0 && sizeof(oalsfx_source_state) % 128 == 0, "an instance's records end where its cache lines end");
+
+
 // What every effect kernel needs to find its instance's data.  Passed by value.
 struct KernelCtx {
     const oalsfx_slot_params* params;   // [instance][slots]
-    oalsfx_slot_state* state;           // [instance][slots]
+    SlotStateLines* state;              // [instance][slots]
     float* const* rings;                // [instance][slots] -> ring slab of that slot (or nullptr)
     const oalsfx_source_params* source; // [instance]
     oalsfx_source_state* source_state;  // [instance]: histories of the send filters
@@ -45,6 +52,12 @@ struct KernelCtx {
                                         // depends on the size of the next call), else 0; the host reads it back lazily
     unsigned* fault;                    // one counter: instances an FP build found not to be steady after all (a broken host invariant: reported
                                         // by the next synchronising call, never silently)
+    // ---- consecutive calls that overlap (batch.cpp: chained launches) ----
+    unsigned* turn;                     // [instance][slots]: the number the last steady-state launch left for the instance; nullptr: off
+    unsigned turn_wait;                 // != 0: an instance starts once its word holds this number (the launch before this one, on another
+                                        // stream, is through with it)
+    unsigned turn_set;                  // != 0: what an instance's word is set to when the launch is through with it
+    unsigned* turn_started;             // the first launch of a run: every workgroup counts itself in here as it starts (k_chain_gate)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
     int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
                               // will not be run on them; one that is not steady after all is counted in `fault`
@@ -135,6 +148,9 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 // `list` (may be nullptr: instances 0 .. instances - 1): the instances to look at (those among them without a filter are skipped)
+// One wavefront that waits until `*started` has reached `target` (the first launch of a run of chained launches has all but a few of its
+// workgroups on the chip): queued in front of the run's second launch.
+void launch_chain_gate(const unsigned* started, unsigned target, unsigned* fault, hipStream_t stream);
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, const int* list, int instances,
                          hipStream_t stream);
 // record k of `packed` (count records of record_bytes, a multiple of 4) goes to slot indices[k] of the device array `dst`

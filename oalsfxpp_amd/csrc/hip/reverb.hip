@@ -136,6 +136,10 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 // requested a tile ahead: so every tap of such an instance must be three tiles away (kPlainMinTap, which host and device share).
 // Measured (scripts/ab_libs.py, profiles/r03g_aligned_windows/): 256-frame calls 43.9 -> 42.3 us (-3.5 %), 512-frame calls -8.5 %,
 // 2048-frame calls 333.8 -> 297.6 us (-10.9 %: 37.2 us per 256 frames, 0.73 of the roofline).
+#ifndef OALSFX_CHAIN_EXP
+#define OALSFX_CHAIN_EXP 0 // experiments: 1 an agent-scope acquire behind the wait for a turn, 2 plain stores of the output frames (timing only),
+                           // 8 no wait at all (negative control of tests/test_gpu_chained.py: it must fail)
+#endif
 #ifndef OALSFX_AW
 #define OALSFX_AW 1
 #endif
@@ -396,6 +400,39 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     oalsfx_reverb_state& S = SS.u.reverb;
     GlobalBytes* slab_b = (GlobalBytes*)(uintptr_t)ctx.rings[sidx];
 
+    // Chained launches: the launch before this one runs on another stream and may still be at work; this instance's turn comes
+    // when that launch is through with it.
+    //  - Everything one launch hands to the next -- delay lines, state, hot records, send-filter histories, this word -- lives in memory
+    //    the L2s do not cache (hipDeviceMallocUncached, batch.cpp): what a wavefront stored is in memory, for every XCD to see, once its
+    //    stores are acknowledged (s_waitcnt vmcnt(0), then the word).  (Agent-scope fences over cached memory -- a write-back of the L2
+    //    per wavefront -- were measured first: 245 us per step instead of 50.)
+    //  - No cache line holds bytes of two instances (SlotStateLines, common.hpp), and nobody but this wavefront reads the instance's
+    //    lines in this launch: this CU's vector L1, emptied when the launch started, holds none of them before the wait is over, and
+    //    needs no invalidate behind it (an agent-scope acquire there -- buffer_inv sc1 -- cost 9 us per step, more than the overlap
+    //    gains; profiles/r03k_chained_launches).  The scalar cache is another matter: it is not written through by vector stores, so a
+    //    line the launch before loaded through it may still be there; s_dcache_inv costs nothing measurable.
+    //  - The wait ends: the launch before has its workgroups on the chip before this one gets its first (batch.cpp, k_chain_gate), and
+    //    a count-out reports through the fault word rather than hang.
+    if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
+        if (valid && lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(ctx.turn + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ctx.turn_wait) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 18)) {
+                    if (ctx.fault) __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+#if OALSFX_CHAIN_EXP & 1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below behind the wait)
+#endif
+        __builtin_amdgcn_s_dcache_inv();
+        __builtin_amdgcn_s_waitcnt(0);
+    }
     const int l4 = lane & 3;
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
     const bool q_valid = lane < 8 * CH && q_chan < nch;
@@ -1424,7 +1461,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (MC || !act) {
                 // stored above / a lane past the end of a ragged call's last tile
             } else if (last) {
-                if (CH == 2) {
+                if (ctx.turn_set != 0u && !(OALSFX_CHAIN_EXP & 2)) {
+                    // chained launches: the caller's buffer is ordinary memory, and two launches may write the same frames from two XCDs:
+                    // written through (agent scope), so that no older line waits in another L2 to be written back over this one
+                    if (CH == 2) {
+                        const unsigned long long both = static_cast<unsigned long long>(__float_as_uint(o0)) | (static_cast<unsigned long long>(__float_as_uint(o1)) << 32);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + static_cast<size_t>(pos_b) * 2), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else __hip_atomic_store(reinterpret_cast<unsigned*>(dst + pos_b), __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (CH == 2) {
                     if (OALSFX_NT & 16) __builtin_nontemporal_store(v2f{o0, o1}, reinterpret_cast<v2f*>(dst + static_cast<size_t>(pos_b) * 2));
                     else *reinterpret_cast<float2*>(dst + static_cast<size_t>(pos_b) * 2) = make_float2(o0, o1);
                 } else dst[pos_b] = o0;
@@ -1527,6 +1571,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             KernelCtx copy = ctx; // a copy made here only: taking the address of the kernel argument itself would park it in scratch for every wave
             reverb_general_call<CH>(&copy, slot, inst, flags & 0xFF, lds, lane);
         }
+    }
+    if (ctx.turn != nullptr && ctx.turn_set != 0u) {
+        // this launch is through with the instance (its stores acknowledged): the next one may take it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+        if (valid && lane == 0) __hip_atomic_store(ctx.turn + sidx, ctx.turn_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(); // state handed back
 }

@@ -1,0 +1,23 @@
+"""Chained launches: step time of the headline loop with consecutive calls overlapping (default) and in plain stream order
+(OALSFX_DEBUG=0x400), instances / frames from the command line.  python3 scripts/chain_probe.py [instances] [frames] [calls]"""
+import sys, time
+sys.path.insert(0, ".")
+import torch
+from oalsfxpp_amd import desc
+from oalsfxpp_amd.api import Batch
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+calls = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+b = Batch(n, desc.FMT_STEREO, 48000, 1)
+b.set_effect_type(0, desc.EAX_REVERB); b.apply_changes()
+src = torch.empty(n * frames * 2, device="cuda").uniform_(-1, 1); dst = torch.empty_like(src)
+for k in range(6):
+    b.mix_device(frames, src.data_ptr(), dst.data_ptr()); b.synchronize()
+for rep in range(3):
+    b.synchronize(); torch.cuda.synchronize()
+    before = b.chained_calls
+    t0 = time.perf_counter()
+    for k in range(calls): b.mix_device(frames, src.data_ptr(), dst.data_ptr())
+    b.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{n} x {frames}: step {dt / calls * 1e6:7.2f} us, {b.chained_calls - before} of {calls} calls chained", flush=True)

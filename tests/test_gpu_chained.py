@@ -1,0 +1,222 @@
+"""GPU parity of chained launches: consecutive `mix_device` calls on the batch's own stream whose step is one steady-state
+reverb launch take turns on two streams, ordered per instance by a word the kernels hand on, so that the tail of one launch overlaps
+with the head of the next.  (What the launches hand on lives in memory the L2s do not cache: no cache is written back in between.)
+
+What has to hold: every output buffer, the effect state and the delay lines are bit-identical to the oracle's, call after call, with
+many calls in flight; anything that is not such a step (property changes, ragged calls, other entry points, read-backs) ends the run
+and comes out in order; a caller that asked for the stream handle gets plain stream order."""
+import numpy as np
+import pytest
+
+from harness import OracleShadow, make_effect, preset_effect, same_bits
+from oalsfxpp_amd import desc
+from oalsfxpp_amd.api import Batch
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+E = make_effect
+
+
+def run_device_calls(b, script, shadows, seed, replicas=True):
+    """`script`: frame counts, or callables run between calls.  Device-resident buffers, one output buffer per call, every input
+    uploaded before the first call and no synchronisation between the calls (the queue is as deep as the script is long); everything
+    is compared afterwards."""
+    import torch
+    for s in shadows.values():
+        s.expected = []
+    bufs = {}
+    for k, op in enumerate(script):
+        if callable(op):
+            continue
+        x = np.stack([orc.synth(seed + i, k, op * b.channels).reshape(op, b.channels) for i in (range(b.n) if b.n <= 128 else [0])])
+        if b.n > 128:   # full size: replicas of one input, the sampled instances with inputs of their own
+            x = np.repeat(x, b.n, axis=0)
+            for i in shadows:
+                x[i] = orc.synth(seed + i, k, op * b.channels).reshape(op, b.channels)
+        dx = torch.from_numpy(x).cuda()
+        bufs[k] = (x, dx, torch.empty_like(dx))
+    torch.cuda.synchronize()
+    pending = []
+
+    def oracle_catches_up():
+        for k in pending:
+            for i, s in shadows.items():
+                s.expected.append(s.oracle.mix(bufs[k][0][i]))
+        pending.clear()
+
+    for k, op in enumerate(script):
+        if callable(op):
+            # (the shadows read the new descriptors back through the C ABI, which ends a run of chained calls and waits: the oracle
+            # mixes what was queued until here first, so that it sees the change where the batch does)
+            oracle_catches_up()
+            op()
+            for s in shadows.values():
+                s.sync()
+            continue
+        x, dx, dy = bufs[k]
+        b.mix_device(op, dx.data_ptr(), dy.data_ptr())
+        pending.append(k)
+    b.synchronize()
+    oracle_catches_up()
+    for c, k in enumerate(sorted(bufs)):
+        x, dx, dy = bufs[k]
+        y = dy.cpu().numpy()
+        for i, s in shadows.items():
+            ok, nbad = same_bits(y[i], s.expected[c])
+            assert ok, f"instance {i}, call {k}: {nbad} samples differ"
+        if b.n > 128 and replicas:
+            rest = np.setdiff1d(np.arange(b.n), list(shadows))
+            r = y[rest].view(np.uint32)
+            assert (r == r[0]).all(), f"call {k}: replicas diverged"
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_chained_calls_match_the_oracle(fmt):
+    n = 70
+    with Batch(n, fmt, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((3 * i) % 113, desc.EAX_REVERB if i % 4 else desc.REVERB) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 2, 3, 17, 35, 36, 68, 69)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)                    # through the start-up cross-fade; proven
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, [256] * 24 + [64, 128, 512, 2048, 256, 256], shadows, 4000)
+        assert b.chained_calls - before >= 28, (before, b.chained_calls)
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+def test_a_run_of_chained_calls_ends_where_it_must():
+    n = 32
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 5, 31)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+
+        def change():
+            b.set_effect(0, preset_effect(20), first=5, count=1)
+            b.set_send_props(-1, 0.7, 0.5, 1.0, first=31, count=1)
+            b.apply_changes()
+
+        script = [256] * 6 + [100] + [256] * 5 + [change] + [256] * 8 + [441, 256, 256, 3000, 256, 256]
+        before = b.chained_calls
+        run_device_calls(b, script, shadows, 5000)
+        assert 0 < b.chained_calls - before < len([op for op in script if not callable(op)])
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+        # a caller that holds the stream handle: plain stream order from then on
+        assert b.stream
+        before = b.chained_calls
+        run_device_calls(b, [256] * 6, shadows, 6000)
+        assert b.chained_calls == before
+        for i, s in shadows.items():
+            assert not s.compare_state()
+
+
+def test_many_chained_calls_at_full_size():
+    """4096 instances (every workgroup slot of the chip taken by each launch): 200 calls without a synchronisation in between, replicas
+    of one input against each other and a sample against the oracle at the end (state and delay lines carry every call's result)."""
+    import torch
+    n, frames, calls = 4096, 256, 200
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        sample = [0, 1, 1023, 2048, 4095]
+        shadows = {i: OracleShadow(b, i) for i in sample}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, frames, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        xs = []
+        for k in range(4):
+            x = np.empty((n, frames, 2), dtype=np.float32)
+            x[:] = orc.synth(9, k, frames * 2).reshape(frames, 2)
+            for i in sample:
+                x[i] = orc.synth(7000 + i, k, frames * 2).reshape(frames, 2)
+            xs.append(x)
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = torch.empty_like(dx[0])
+        torch.cuda.synchronize()
+        before = b.chained_calls
+        for k in range(calls):
+            b.mix_device(frames, dx[k % 4].data_ptr(), dy.data_ptr())
+        b.synchronize()
+        assert b.chained_calls - before == calls
+        y = dy.cpu().numpy()
+        ref = {}
+        for i, s in shadows.items():
+            for k in range(calls):
+                ref[i] = s.oracle.mix(xs[k % 4][i])
+            ok, nbad = same_bits(y[i], ref[i])
+            assert ok, f"instance {i}: {nbad} samples of the last buffer differ"
+        rest = np.setdiff1d(np.arange(n), sample)
+        r = y[rest]
+        assert (r.view(np.uint32) == r[0].view(np.uint32)).all(), "replicas diverged"
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+def test_a_run_that_starts_behind_a_full_queue():
+    """The first launch of a run sits behind unfinished work of its stream while the second, on the other stream, could start at once:
+    its workgroups wait for the first's, so it must not take the chip before the first has (k_chain_gate).  4096 instances fill every
+    workgroup slot of the chip; long unchained calls (3000 frames: three launches each) in front of each run."""
+    n = 4096
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1023, 2049, 4095)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, [3000, 3000] + [256] * 12 + [3000] + [256] * 12 + [1000] + [128] * 12, shadows, 8000)
+        assert b.chained_calls - before == 36
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+def test_chained_calls_with_every_preset_at_full_size():
+    """Uneven load: 4096 instances over the 113 presets (every kind of steady-state build in one grid, buffers that take different times),
+    150 calls without a synchronisation; a sample against the oracle -- every buffer, then state and delay lines."""
+    n = 4096
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect(i % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 5, 26, 112, 113, 1000, 2047, 2048, 3333, 4094, 4095)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, [256] * 150, shadows, 11000, replicas=False)
+        assert b.chained_calls - before == 150
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
