@@ -112,6 +112,7 @@ struct oalsfx_batch {
     unsigned* d_inst_epoch = nullptr;             // [n]
     unsigned* d_exact = nullptr;                  // [n*slots] "settled and at rest" as the reverb kernels left it
     unsigned* h_exact = nullptr;                  // pinned copy of d_exact, filled by the read-back
+    char fault_text[200] = {};
     unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
     unsigned* d_fault = nullptr;                  // device address of h_fault
     hipEvent_t ev_exact = nullptr;
@@ -171,9 +172,9 @@ struct oalsfx_batch {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_chain = nullptr;
     hipEvent_t ev_chain_start = nullptr;          // recorded in front of a run's first launch: the second (other stream) starts no earlier
-    unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups that first launches of runs started (k_chain_gate)
+    unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups of chained launches that have started (k_chain_gate)
     uint32_t turn_counter = 0;                    // the number the last chained launch set
-    uint32_t started_total = 0;                   // what that count comes to once the first launch of the last run has started as a whole
+    uint32_t started_total = 0;                   // what that count comes to once the last chained launch has started as a whole
     int chain_len = 0;                            // launches in the current run
     int resident_groups = 0;                      // workgroups of a steady-state reverb launch the device holds at once (4 per CU)
     bool uncached = false;                        // what launches hand on lives in uncached memory: calls can be chained launches
@@ -1061,6 +1062,12 @@ void poll_exact(oalsfx_batch* b)
 bool check_fault(oalsfx_batch* b)
 {
     if (!b->h_fault || *b->h_fault == 0) return true;
+    const unsigned f = *b->h_fault;
+    if (f >= oalsfx_hip::kFaultTurn) {
+        std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady).",
+                      f, (f / oalsfx_hip::kFaultTurn) & 0xFFFu, f / oalsfx_hip::kFaultGate, f & 0xFFFu);
+        return b->fail(b->fault_text);
+    }
     return b->fail("Internal error: a reverb instance listed as proven steady was not; its buffer was left unprocessed.");
 }
 
@@ -1112,9 +1119,19 @@ bool chain_eligible(oalsfx_batch* b, int frames, hipStream_t stream)
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
     if (!b->dirty_list.empty() || b->lists_dirty || b->exact_wanted) return false;
-    if (b->slots != 1 || b->channels > 2 || b->n_filtered > 0 || frames > OALSFX_MAX_CHUNK || (frames & 63) != 0) return false;
+    if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK || (frames & 63) != 0) return false;
     const int steady = b->fast_count[0] + b->slow_count[0];
     if (steady != b->n || b->general_count[0] != 0) return false;
+    if (b->n_filtered > 0) {
+        // send filters: only when every filtered instance's build has them inside (no pre-pass launch in front of the reverb's)
+        KernelCtx ctx{};
+        ctx.frames = frames;
+        const SlotPlan p0 = plan_slot(b, ctx, 0, frames, true);
+        if (!p0.by_kind || p0.steady != b->n) return false;
+        int counts[4];
+        steady_kind_counts(b, 0, p0.proven_usable, counts);
+        if (filters_inside_count(b, 0, counts) != b->n_filtered) return false;
+    }
     // (k_reverb_steady_kinds: a kind's incomplete workgroup goes to the next kind, steady_kind_counts: the grid is exactly this long)
     return (b->n + 3) / 4 <= b->resident_groups;
 }
@@ -1162,19 +1179,27 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
         if (++b->turn_counter == 0u) b->turn_counter = 1u;
         ctx.turn_set = b->turn_counter;
+        // A launch whose workgroups wait for the launch before must not take the chip before that launch has its workgroups on it: they
+        // would wait for workgroups that cannot start.  Stream order does not see to that (this launch comes behind the launch two
+        // before it, on its own stream; the launch before it sits in another queue, which the hardware may get to later -- the first
+        // launch ever on the second stream waited for its queue to be set up while the third launch of the run filled the chip).  So
+        // every workgroup of a chained launch counts itself in as it starts, and every launch but a run's first comes behind a gate
+        // (one wavefront, k_chain_gate) that waits until all but a few workgroups of the launch before have.  Then a workgroup that
+        // waits always waits for one that is on the chip or through: at most those few are not, fewer than the chip has places.
         unsigned* started = b->d_turn + static_cast<size_t>(b->n) * b->slots;
         if (!b->chain_open) {
-            // the first of a run: its workgroups count themselves in as they start
             if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
-            ctx.turn_started = started;
-            b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
             b->chain_len = 1;
-        } else if (b->chain_len++ == 1) {
-            // the second (the first on the other stream, and the first whose workgroups wait): not before the first could start, and
-            // then not before all but a few of the first's workgroups are on the chip (k_chain_gate)
-            if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
-            oalsfx_hip::launch_chain_gate(started, b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1)), b->d_fault, stream);
+        } else {
+            // (the second of a run is the first on the other stream: not before the first could start either)
+            if (b->chain_len++ == 1 && !b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
+            // (0x800: the gate in front of a run's second launch only, as first built -- the negative control of
+            // tests/test_gpu_chained.py::test_the_first_run_of_a_fresh_process)
+            if (b->chain_len == 2 || !(debug_flags() & 0x800))
+                oalsfx_hip::launch_chain_gate(started, b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1)), b->d_fault, stream);
         }
+        ctx.turn_started = started;
+        b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
         b->chain_open = true;
         b->chained_calls += 1;
     }
@@ -1375,8 +1400,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
         b->resident_groups = 4 * cus;
         // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
         const char* kind = std::getenv("OALSFX_RING_MEMORY");
-        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances + 3) / 4 <= b->resident_groups && !(debug_flags() & 0x400) &&
-                      (!kind || std::strcmp(kind, "uncached") == 0);
+        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances + 3) / 4 <= b->resident_groups && (!kind || std::strcmp(kind, "uncached") == 0);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");

@@ -57,7 +57,7 @@ struct KernelCtx {
     unsigned turn_wait;                 // != 0: an instance starts once its word holds this number (the launch before this one, on another
                                         // stream, is through with it)
     unsigned turn_set;                  // != 0: what an instance's word is set to when the launch is through with it
-    unsigned* turn_started;             // the first launch of a run: every workgroup counts itself in here as it starts (k_chain_gate)
+    unsigned* turn_started;             // every workgroup counts itself in here as it starts (k_chain_gate)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
     int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
                               // will not be run on them; one that is not steady after all is counted in `fault`
@@ -148,8 +148,13 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 // `list` (may be nullptr: instances 0 .. instances - 1): the instances to look at (those among them without a filter are skipped)
-// One wavefront that waits until `*started` has reached `target` (the first launch of a run of chained launches has all but a few of its
-// workgroups on the chip): queued in front of the run's second launch.
+// The fault word (KernelCtx::fault, host memory): instances a proven-steady launch had to leave alone count 1 each; waits of chained
+// launches that gave up count in fields of their own
+constexpr unsigned kFaultTurn = 1u << 12; // an instance's turn did not come (reverb.hip)
+constexpr unsigned kFaultGate = 1u << 24; // k_chain_gate counted out
+
+// One wavefront that waits until `*started` has reached `target` (the chained launch before has all but a few of its workgroups on the
+// chip): queued in front of every chained launch but a run's first.
 void launch_chain_gate(const unsigned* started, unsigned target, unsigned* fault, hipStream_t stream);
 void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_stride, float* filtered, size_t send_floats, const int* list, int instances,
                          hipStream_t stream);

@@ -419,8 +419,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             unsigned spins = 0;
             while (__hip_atomic_load(ctx.turn + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ctx.turn_wait) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 18)) {
-                    if (ctx.fault) __hip_atomic_fetch_add(ctx.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (++spins > (1u << 20)) {
+                    if (ctx.fault) __hip_atomic_fetch_add(ctx.fault, kFaultTurn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }

@@ -255,17 +255,16 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
 }
 
 // Chained launches (batch.cpp): a launch whose workgroups wait for the launch before must not take the chip before that
-// launch has its workgroups on it.  In a run that holds by itself from the third launch on (a launch starts when the launch two before
-// it has completed, and by then the launch before it has taken over every workgroup slot that one freed); the second launch of a run
-// comes behind this gate.
+// launch has its workgroups on it; every chained launch but a run's first comes behind this gate.  (In the steady state of a run it
+// finds its count reached: the launch before has been taking over the places of the launch two before, which has just completed.)
 __global__ __launch_bounds__(64) void k_chain_gate(const unsigned* started, unsigned target, unsigned* fault)
 {
     if (threadIdx.x != 0) return;
     unsigned spins = 0;
     while (static_cast<int>(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 20)) {
-            if (fault) __hip_atomic_fetch_add(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (++spins > (1u << 22)) {
+            if (fault) __hip_atomic_fetch_add(fault, kFaultGate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }

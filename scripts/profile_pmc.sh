@@ -6,11 +6,15 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 cd $R
 export OALSFX_TRAFFIC_REFRESH=1   # bench.py must not insist on a traffic.json of this build: these passes produce it
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --steps 50 --warmup 64 --no-cpu-baseline > $O/bench_trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc1.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq2 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc3.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline > $O/bench_pmc4.log 2>&1
+# calls in plain stream order (--no-chain): a launch's duration is then the kernel's own, which is what bench.py's roofline object reports
+# (its event-timed region runs one launch after the other as well); the product's default, consecutive calls overlapping, is traced
+# beside it -- there a launch's duration includes its wait for the launch before, and two launches are in flight at a time
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --steps 50 --warmup 64 --no-cpu-baseline --no-chain > $O/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chained -o t -- python3 bench.py --steps 50 --warmup 64 --no-cpu-baseline --no-kernel-timing > $O/bench_trace_chained.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline --no-chain > $O/bench_pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq2 -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline --no-chain > $O/bench_pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline --no-chain > $O/bench_pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 bench.py --steps 10 --warmup 64 --no-cpu-baseline --no-chain > $O/bench_pmc4.log 2>&1
 O=$O python3 - <<'PY'
 import csv, glob, os, collections
 O=os.environ["O"]

@@ -220,3 +220,72 @@ def test_chained_calls_with_every_preset_at_full_size():
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_chained_calls_with_send_filters_inside(fmt):
+    """Shelf filters on the direct and the auxiliary send of most instances, plain and close-tap presets (the two kinds whose builds filter
+    their own sends, tests/test_gpu_filters_inside.py): no pre-pass launch, so these steps chain as well -- the filters' histories are
+    among what one launch hands to the next."""
+    sends = [(-1, 0.9, 0.5, 1.0), (0, 0.8, 1.0, 0.4), (-1, 1.0, 0.3, 0.6), (0, 0.7, 0.25, 0.5), (-1, 0.6, 1.0, 0.2)]
+    n = 70
+    with Batch(n, fmt, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((0, 2)[i % 2], desc.EAX_REVERB if i % 3 else desc.REVERB) for i in range(n)])
+        for i in range(n):
+            if i % 4 == 3:
+                continue
+            for k in range(1 + i % 2):
+                slot, g, hf, lf = sends[(i + k) % len(sends)]
+                b.set_send_props(slot, g, hf, lf, first=i, count=1)
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 2, 3, 4, 5, 33, 34, 35, 68, 69)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, [256] * 20 + [64, 2048, 256, 128] + [256] * 6, shadows, 12000)
+        assert b.chained_calls - before == 30, (before, b.chained_calls)
+        assert b.last_reverb_kernel.replace(" ", "").endswith(",true>"), b.last_reverb_kernel   # (SF: the last template argument)
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:4])
+
+
+def test_the_first_run_of_a_fresh_process():
+    """The first launch ever on the batch's second stream waits for its hardware queue to be set up; the third launch of the run, on
+    the first stream, is not held up by that and would fill the chip with workgroups that wait for the second launch's -- which then
+    cannot start.  (That is how this was found: the first batch of a process, 4096 instances, counted out.)  Every chained launch
+    therefore comes behind a gate that waits until the launch before it has its workgroups on the chip."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, '.')\n"
+        "import torch\n"
+        "from oalsfxpp_amd import desc\n"
+        "from oalsfxpp_amd.api import Batch\n"
+        "n, frames = 4096, 256\n"
+        "b = Batch(n, desc.FMT_STEREO, 48000, 1)\n"
+        "from oalsfxpp_amd import lib\n"
+        "def effect(i):\n"
+        "    e = lib.effect_defaults(desc.EAX_REVERB); e.props.reverb = lib.preset(i)[1]; return e\n"
+        "b.set_effect(0, [effect((0, 4, 5, 6, 7, 8)[i % 6]) for i in range(n)]); b.apply_changes()\n"
+        "src = torch.empty(n * frames * 2, device='cuda').uniform_(-1, 1); dst = torch.empty_like(src)\n"
+        "for k in range(6):\n"
+        "    b.mix_device(frames, src.data_ptr(), dst.data_ptr()); b.synchronize()\n"
+        "for k in range(64):\n"
+        "    b.mix_device(frames, src.data_ptr(), dst.data_ptr())\n"
+        "b.synchronize()\n"
+        "print('chained', b.chained_calls)\n"
+    )
+    env = dict(os.environ)
+    if env.get("OALSFX_TEST_NEGATIVE_CONTROL"):
+        env["OALSFX_DEBUG_FLAGS"] = "0x800"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "chained 6" in r.stdout, r.stdout      # 4 single calls after the first two (not proven yet) + the 64
