@@ -176,6 +176,7 @@ struct oalsfx_batch {
     uint32_t turn_counter = 0;                    // the number the last chained launch set
     uint32_t started_total = 0;                   // what that count comes to once the last chained launch has started as a whole
     int chain_len = 0;                            // launches in the current run
+    std::vector<std::pair<const char*, const char*>> chain_dsts; // ... and their output buffers
     int resident_groups = 0;                      // workgroups of a steady-state reverb launch the device holds at once (4 per CU)
     bool uncached = false;                        // what launches hand on lives in uncached memory: calls can be chained launches
     bool chain_open = false;                      // the last call was a chained launch (its kernel may still run, on either stream)
@@ -1112,8 +1113,23 @@ bool chain_join(oalsfx_batch* b)
 // Can this call be a chained launch?  The batch's own stream, nobody holding its handle, nothing to upload, no per-launch events, one
 // chunk of whole tiles, and a step that is exactly one steady-state launch of at most as many workgroups as the chip holds at once
 // (then the launch before is resident as a whole before this one gets a workgroup, and no wait on a turn word can starve).
-bool chain_eligible(oalsfx_batch* b, int frames, hipStream_t stream)
+bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream)
 {
+    if (b->chain_open && b->chain_dsts.size() >= 256) {
+        // (a caller that hands in a fresh output buffer with every call: the list of a run's output buffers starts over with a new run)
+        const char* lo = reinterpret_cast<const char*>(dst);
+        bool known = false;
+        for (const auto& d : b->chain_dsts) known |= d.first <= lo && lo < d.second;
+        if (!known) return false;
+    }
+    // an input that is the output of a call of the current run (a feedback loop through the caller's buffers): stream order for this one
+    {
+        const char* lo = reinterpret_cast<const char*>(src);
+        const char* hi = lo + static_cast<size_t>(b->n) * frames * b->channels * sizeof(float);
+        if (b->chain_open)
+            for (const auto& d : b->chain_dsts)
+                if (lo < d.second && d.first < hi) return false;
+    }
     if (stream != b->stream || b->stream_handed_out || (debug_flags() & (0x400 | 8)) || b->timing_every > 0 || b->d_timeline) return false;
     if (!b->uncached) return false;
     for (const auto& kv : b->pools)
@@ -1139,7 +1155,7 @@ bool chain_eligible(oalsfx_batch* b, int frames, hipStream_t stream)
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream, bool may_chain = false)
 {
     poll_exact(b);
-    const bool chained = may_chain && chain_eligible(b, frames, stream);
+    const bool chained = may_chain && chain_eligible(b, frames, src, dst, stream);
     if (!chained && !chain_join(b)) return false;
     if (chained) {
         // take turns on the two streams; the first of a run stays on the batch's stream, behind whatever was queued there before
@@ -1187,6 +1203,14 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         // (one wavefront, k_chain_gate) that waits until all but a few workgroups of the launch before have.  Then a workgroup that
         // waits always waits for one that is on the chip or through: at most those few are not, fewer than the chip has places.
         unsigned* started = b->d_turn + static_cast<size_t>(b->n) * b->slots;
+        {
+            const char* lo = reinterpret_cast<const char*>(dst);
+            const char* hi = lo + static_cast<size_t>(b->n) * frames * b->channels * sizeof(float);
+            if (!b->chain_open) b->chain_dsts.clear();
+            bool known = false;
+            for (auto& d : b->chain_dsts) known |= d.first <= lo && hi <= d.second;
+            if (!known) b->chain_dsts.push_back({lo, hi});
+        }
         if (!b->chain_open) {
             if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
             b->chain_len = 1;

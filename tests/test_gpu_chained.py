@@ -289,3 +289,36 @@ def test_the_first_run_of_a_fresh_process():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "chained 6" in r.stdout, r.stdout      # 4 single calls after the first two (not proven yet) + the 64
+
+
+def test_feedback_through_the_callers_buffers():
+    """A call whose input is the output of the call before (still in flight, perhaps): legal in stream order, so such a call is not
+    overlapped with its predecessor -- its input frames are ordinary memory, which the predecessor's XCDs and this call's need not
+    agree on."""
+    import torch
+    n, frames = 70, 256
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((5 * i) % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 34, 35, 69)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, frames, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        x = np.stack([orc.synth(13000 + i, 0, frames * 2).reshape(frames, 2) for i in range(n)]) * np.float32(0.25)
+        bufs = [torch.from_numpy(x).cuda(), torch.zeros(n, frames, 2, device="cuda")]
+        torch.cuda.synchronize()
+        calls = 12
+        for k in range(calls):
+            b.mix_device(frames, bufs[k % 2].data_ptr(), bufs[(k + 1) % 2].data_ptr())
+        b.synchronize()
+        y = bufs[calls % 2].cpu().numpy()
+        for i, s in shadows.items():
+            v = x[i]
+            for k in range(calls):
+                v = s.oracle.mix(v)
+            ok, nbad = same_bits(y[i], v)
+            assert ok, f"instance {i}: {nbad} samples differ after {calls} calls through two buffers"
