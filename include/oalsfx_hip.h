@@ -86,6 +86,8 @@ int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, f
 int oalsfx_batch_synchronize(oalsfx_batch* b);
 /* How many oalsfx_batch_mix_device calls overlapped with their neighbours that way so far (tests, benchmark records). */
 long long oalsfx_batch_chained_calls(const oalsfx_batch* b);
+/* Measurement: of the instance hand-overs between chained calls so far, how many stayed on one CU (those pay for an L1 invalidate). Waits. */
+long long oalsfx_debug_chain_same_cu(oalsfx_batch* b);
 /* Api::mix for a caller that streams buffer after buffer from host memory (what the reference's only entry point is used for,
  * src/oalsfxpp.cpp:3785-3829, src/oalsfxpp_test.cpp:891): returns as soon as the call is queued.  The copy in of call k + 1, the
  * kernels of call k and the copy out of call k - 1 overlap on three streams, ordered by events.  `src_host` and `dst_host` must stay

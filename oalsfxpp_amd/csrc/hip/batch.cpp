@@ -106,7 +106,10 @@ struct oalsfx_batch {
     float* d_filtered = nullptr;                  // [1 + slots][n][chunk frames][channels] outputs of the send-filter pre-pass
     size_t filtered_capacity = 0;                 // floats per send plane
     float* d_mixbuf = nullptr;
-    int* d_lists = nullptr;                       // [slots][n]
+    int* d_lists = nullptr;                       // [slots][n]: the one of d_lists_buf the next launches read
+    int* d_lists_buf[2] = {};                     // every rebuilt list goes to the other buffer: a launch that is still in flight -- chained
+                                                  // launches -- keeps reading the list it was given
+    int lists_turn = 0;
     int* d_progress = nullptr;                    // [n*slots] hand-off from the steady-state reverb kernel to the general kernel behind it
     unsigned* d_hot = nullptr;                    // [n*slots][hot::SIZE] start records of the proven-steady reverb kernel
     unsigned* d_inst_epoch = nullptr;             // [n]
@@ -545,11 +548,25 @@ oalsfx_batch::Stage* acquire_stage(oalsfx_batch* b, size_t bytes)
 // Folds all pending property changes into descriptors, device state and the launch plan: what the
 // reference does lazily at the top of mix_data (update_context_sources, src/oalsfxpp.cpp:3397-3412)
 // plus EffectSlot::set_effect's state re-creation (src/oalsfxpp.cpp:2688-2709).
-// Everything is enqueued on the batch's own stream without waiting for it; `consumer` (the stream the next launches go
-// to) is made to wait for the uploads with an event when it is a different stream.
-bool sync_params(oalsfx_batch* b, hipStream_t consumer)
+// In two steps: prepare_params does the host's part and packs the staging buffer; launch_params puts it in place on a stream.
+// (sync_params: both, on the batch's own stream, without waiting for it; `consumer` -- the stream the next launches go to -- is made to
+// wait for the uploads with an event when it is a different stream.  mix_device looks at what was prepared before it decides where the
+// call's launches go: chained launches.)
+struct PendingUpload {
+    bool any = false;                  // something had changed
+    oalsfx_batch::Stage* st = nullptr; // nullptr: nothing to upload
+    size_t bytes = 0;
+    bool direct = true;                // read by the kernel straight from the page-locked buffer
+    bool chainable = true;             // only records that can take their turn instance by instance (slot parameters, epochs) and lists
+    oalsfx_hip::UploadJobs jobs{};
+};
+
+bool chain_join(oalsfx_batch* b);
+
+bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
 {
     if (b->dirty_list.empty() && !b->lists_dirty) return true;
+    pu.any = true;
     const size_t total = static_cast<size_t>(b->n) * b->slots;
     std::map<size_t, int> need; // size class -> slabs needed
     std::vector<size_t> restarted;
@@ -642,6 +659,9 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         b->inst_dirty[i] = 0;
     }
     b->dirty_list.clear();
+
+    // slots that start over take and give back delay lines, which launches of a run of chained launches may still be at work on
+    if (!restarted.empty() && !chain_join(b)) return false;
 
     // ring slabs: grow each size class once, zero fresh chunks in one memset
     for (auto& kv : need) {
@@ -774,29 +794,55 @@ bool sync_params(oalsfx_batch* b, hipStream_t consumer)
         // Bulk uploads (creation of a batch) keep the transfer.
         const bool direct = off <= (static_cast<size_t>(1) << 20) && !(debug_flags() & 0x10000000);
         const char* from = direct ? st->host : st->dev;
-        if (!direct && !b->hip_ok(hipMemcpyAsync(st->dev, st->host, off, hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(parameters)")) return false;
         // one launch puts everything in place
         auto words = [&](size_t o) { return reinterpret_cast<const unsigned*>(from + o); };
         auto ints = [&](size_t o) { return reinterpret_cast<const int*>(from + o); };
-        oalsfx_hip::UploadJobs jobs{};
-        jobs.scatter[0] = {reinterpret_cast<unsigned*>(b->d_params), words(o_pr), ints(o_pi), static_cast<int>(sizeof(oalsfx_slot_params) / 4), static_cast<int>(n_p)};
-        jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_hip::SlotStateLines) / 4), static_cast<int>(n_s)};
-        jobs.scatter[2] = {reinterpret_cast<unsigned*>(b->d_source), words(o_cr), ints(o_ci), static_cast<int>(sizeof(oalsfx_source_params) / 4), static_cast<int>(n_src)};
-        jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ti), 1, static_cast<int>(n_t)};
+        if (rebuild_lists) b->d_lists = b->d_lists_buf[b->lists_turn ^= 1]; // (launches in flight keep the list they were given)
+        oalsfx_hip::UploadJobs& jobs = pu.jobs;
+        jobs = oalsfx_hip::UploadJobs{};
+        // (slot parameters and epochs take their turn instance by instance when the upload runs beside the launch before it)
+        jobs.scatter[0] = {reinterpret_cast<unsigned*>(b->d_params), words(o_pr), ints(o_pi), static_cast<int>(sizeof(oalsfx_slot_params) / 4), static_cast<int>(n_p), 1};
+        jobs.scatter[1] = {reinterpret_cast<unsigned*>(b->d_state), words(o_sr), ints(o_si), static_cast<int>(sizeof(oalsfx_hip::SlotStateLines) / 4), static_cast<int>(n_s), 0};
+        jobs.scatter[2] = {reinterpret_cast<unsigned*>(b->d_source), words(o_cr), ints(o_ci), static_cast<int>(sizeof(oalsfx_source_params) / 4), static_cast<int>(n_src), 0};
+        jobs.scatter[3] = {reinterpret_cast<unsigned*>(b->d_inst_epoch), words(o_ep), ints(o_ti), 1, static_cast<int>(n_t), 1};
         jobs.copy[0] = {reinterpret_cast<unsigned*>(b->d_rings), words(o_rt), rings_changed ? total * (sizeof(float*) / 4) : 0, 0};
         jobs.copy[1] = {reinterpret_cast<unsigned*>(b->d_lists), words(o_li), rebuild_lists ? total : 0, 0};
-        oalsfx_hip::launch_upload(jobs, b->stream);
+        pu.st = st;
+        pu.bytes = off;
+        pu.direct = direct;
+        pu.chainable = direct && n_s == 0 && n_src == 0 && !rings_changed && need.empty();
+    }
+    return true;
+}
+
+// `turn` / `turn_wait`: the upload runs beside a chained launch that may still be at work (see UploadJobs).
+bool launch_params(oalsfx_batch* b, PendingUpload& pu, hipStream_t upload_stream, hipStream_t consumer, const unsigned* turn = nullptr, unsigned turn_wait = 0)
+{
+    if (pu.st) {
+        oalsfx_batch::Stage* st = pu.st;
+        pu.st = nullptr;
+        if (!pu.direct && !b->hip_ok(hipMemcpyAsync(st->dev, st->host, pu.bytes, hipMemcpyHostToDevice, upload_stream), "hipMemcpyAsync(parameters)")) return false;
+        pu.jobs.turn = turn;
+        pu.jobs.turn_wait = turn_wait;
+        pu.jobs.fault = b->d_fault;
+        oalsfx_hip::launch_upload(pu.jobs, upload_stream);
         // the staging buffer is free again once everything that reads it has run
-        if (!b->hip_ok(hipEventRecord(st->done, b->stream), "hipEventRecord")) return false;
+        if (!b->hip_ok(hipEventRecord(st->done, upload_stream), "hipEventRecord")) return false;
         st->pending = true;
         if (!b->hip_ok(hipGetLastError(), "parameter upload")) return false;
     }
-    // the uploads ran on the batch's own stream; a caller-supplied launch stream must see them
-    if (consumer && consumer != b->stream) {
-        if (!b->hip_ok(hipEventRecord(b->ev_uploaded, b->stream), "hipEventRecord")) return false;
+    // a launch stream other than the one the uploads ran on must see them
+    if (pu.any && consumer && consumer != upload_stream) {
+        if (!b->hip_ok(hipEventRecord(b->ev_uploaded, upload_stream), "hipEventRecord")) return false;
         if (!b->hip_ok(hipStreamWaitEvent(consumer, b->ev_uploaded, 0), "hipStreamWaitEvent")) return false;
     }
     return true;
+}
+
+bool sync_params(oalsfx_batch* b, hipStream_t consumer)
+{
+    PendingUpload pu;
+    return prepare_params(b, pu) && launch_params(b, pu, b->stream, consumer);
 }
 
 bool ensure_mixbuf(oalsfx_batch* b)
@@ -1134,7 +1180,6 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     if (!b->uncached) return false;
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
-    if (!b->dirty_list.empty() || b->lists_dirty || b->exact_wanted) return false;
     if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK || (frames & 63) != 0) return false;
     const int steady = b->fast_count[0] + b->slow_count[0];
     if (steady != b->n || b->general_count[0] != 0) return false;
@@ -1155,14 +1200,20 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream, bool may_chain = false)
 {
     poll_exact(b);
-    const bool chained = may_chain && chain_eligible(b, frames, src, dst, stream);
+    // what has changed since the last call: the host's part first (it decides what this call launches), the upload itself below, where
+    // the call's launches go
+    PendingUpload upload;
+    if (!prepare_params(b, upload)) return false;
+    const bool chained = may_chain && (!upload.st || upload.chainable) && chain_eligible(b, frames, src, dst, stream);
     if (!chained && !chain_join(b)) return false;
+    hipStream_t const caller_stream = stream;
     if (chained) {
         // take turns on the two streams; the first of a run stays on the batch's stream, behind whatever was queued there before
         b->chain_on_second = b->chain_open && !b->chain_on_second;
         stream = b->chain_on_second ? b->stream2 : b->stream;
     }
-    if (!sync_params(b, stream)) return false;
+    (void)caller_stream;
+    if (!chained && !launch_params(b, upload, b->stream, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
     b->timing = b->timing_every > 0 && (b->mix_calls++ % b->timing_every) == 0;
     const bool filtered = b->n_filtered > 0;
@@ -1192,6 +1243,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.no_follow_up = 0;
     if (chained) {
         ctx.turn = b->d_turn;
+        ctx.turn_cu = b->d_turn + static_cast<size_t>(b->n) * b->slots + 16;
         ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
         if (++b->turn_counter == 0u) b->turn_counter = 1u;
         ctx.turn_set = b->turn_counter;
@@ -1224,6 +1276,10 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         }
         ctx.turn_started = started;
         b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
+        // Parameters that changed since the call before: put in place on this launch's stream, behind the gate -- beside the launch
+        // before, which may still be at work with the old ones: a slot's record (and its instance's epoch) is stored once that launch is
+        // through with the instance; a rebuilt list went to the buffer that launch does not read.
+        if (!launch_params(b, upload, stream, nullptr, b->d_turn, ctx.turn_wait)) return false;
         b->chain_open = true;
         b->chained_calls += 1;
     }
@@ -1424,7 +1480,11 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
         b->resident_groups = 4 * cus;
         // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
         const char* kind = std::getenv("OALSFX_RING_MEMORY");
-        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances + 3) / 4 <= b->resident_groups && (!kind || std::strcmp(kind, "uncached") == 0);
+        // (whole workgroups only: the idle wavefronts of an incomplete workgroup run beside the first instance of their kind's list and read
+        // its records without waiting for its turn -- old lines in that CU's L1, found with 70 instances; every kind but the last is
+        // whole workgroups anyway, steady_kind_counts)
+        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances & 3) == 0 && n_instances / 4 <= b->resident_groups &&
+                      (!kind || std::strcmp(kind, "uncached") == 0);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
@@ -1440,15 +1500,16 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists), total * sizeof(int)), "hipMalloc(lists)");
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists_buf[0]), 2 * total * sizeof(int)), "hipMalloc(lists)");
+    if (ok) { b->d_lists_buf[1] = b->d_lists_buf[0] + total; b->d_lists = b->d_lists_buf[0]; }
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_hot), total * oalsfx_hip::hot::SIZE * sizeof(unsigned)), "hipMalloc(hot records)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_hot, 0, total * oalsfx_hip::hot::SIZE * sizeof(unsigned), b->stream), "hipMemsetAsync(hot records)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_inst_epoch), n_instances * sizeof(unsigned)), "hipMalloc(epochs)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_inst_epoch, 0, n_instances * sizeof(unsigned), b->stream), "hipMemsetAsync(epochs)");
-    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_turn), (total + 16) * sizeof(unsigned)), "hipMalloc(turns)");
-    ok = ok && b->hip_ok(hipMemsetAsync(b->d_turn, 0, (total + 16) * sizeof(unsigned), b->stream), "hipMemsetAsync(turns)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_turn), (2 * total + 16) * sizeof(unsigned)), "hipMalloc(turns)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_turn, 0, (2 * total + 16) * sizeof(unsigned), b->stream), "hipMemsetAsync(turns)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_exact, 0, total * sizeof(unsigned), b->stream), "hipMemsetAsync(exact)");
     ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_exact), total * sizeof(unsigned)), "hipHostMalloc(exact)");
@@ -1490,7 +1551,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     for (hipEvent_t e : b->event_pool) hipEventDestroy(e);
     for (void* c : b->chunks) handed_on_free(c);
     hipFree(b->d_params); handed_on_free(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); handed_on_free(b->d_source_state); hipFree(b->d_filtered);
-    hipFree(b->d_mixbuf); hipFree(b->d_lists); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    hipFree(b->d_mixbuf); hipFree(b->d_lists_buf[0]); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     handed_on_free(b->d_hot); hipFree(b->d_inst_epoch); handed_on_free(b->d_exact); handed_on_free(b->d_turn);
     if (b->ev_chain) hipEventDestroy(b->ev_chain);
     if (b->ev_chain_start) hipEventDestroy(b->ev_chain_start);
@@ -1910,6 +1971,15 @@ int oalsfx_batch_plan(oalsfx_batch* b, int slot, int counts[4])
 const char* oalsfx_batch_last_reverb_kernel(const oalsfx_batch* b) { return b->last_steady_kernel; }
 
 long long oalsfx_batch_chained_calls(const oalsfx_batch* b) { return b->chained_calls; }
+
+long long oalsfx_debug_chain_same_cu(oalsfx_batch* b)
+{
+    // how many instance hand-overs of chained launches stayed on one CU (and paid for an L1 invalidate) so far
+    unsigned v = 0;
+    if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || hipStreamSynchronize(b->stream) != hipSuccess) return -1;
+    if (hipMemcpy(&v, b->d_turn + static_cast<size_t>(b->n) * b->slots + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 
 int oalsfx_device_pci_bus_id(int device_id, char* out, int len)
 {

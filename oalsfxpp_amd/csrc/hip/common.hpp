@@ -58,6 +58,7 @@ struct KernelCtx {
                                         // stream, is through with it)
     unsigned turn_set;                  // != 0: what an instance's word is set to when the launch is through with it
     unsigned* turn_started;             // every workgroup counts itself in here as it starts (k_chain_gate)
+    unsigned* turn_cu;                  // [instance][slots]: the CU the last chained launch ran the instance on (reverb.hip, this_cu)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
     int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
                               // will not be run on them; one that is not steady after all is counted in `fault`
@@ -162,9 +163,11 @@ void launch_send_filters(const KernelCtx& ctx, const float* src, long long src_s
 void launch_scatter_records(void* dst, size_t record_bytes, const void* packed, const int* indices, int count, hipStream_t stream);
 // A whole parameter upload in one launch: record k of `packed` goes to slot indices[k] of `dst` (four arrays), and two plain copies
 // (dword counts; 16-byte aligned).  Sources may be page-locked host memory.
-struct ScatterJob { unsigned* dst; const unsigned* packed; const int* indices; int record_dwords; int count; };
+struct ScatterJob { unsigned* dst; const unsigned* packed; const int* indices; int record_dwords; int count; int takes_turns; };
 struct CopyJob { unsigned* dst; const unsigned* src; size_t dwords; int blocks; };
-struct UploadJobs { ScatterJob scatter[4]; CopyJob copy[2]; };
+// turn / turn_wait / fault (chained launches, batch.cpp): a record of a job that takes turns is stored once the launch before is through
+// with the instance it belongs to (the word turn[indices[k]] holds turn_wait); nullptr / 0: at once
+struct UploadJobs { ScatterJob scatter[4]; CopyJob copy[2]; const unsigned* turn; unsigned turn_wait; unsigned* fault; };
 void launch_upload(UploadJobs jobs, hipStream_t stream);
 void launch_null(hipStream_t stream);
 // dst[0 .. floats) = src[0 .. floats), either of them possibly page-locked host memory mapped into the device's address space

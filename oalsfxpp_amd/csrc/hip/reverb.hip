@@ -351,6 +351,13 @@ struct SteadyShared {
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
 // kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
+// The CU this wavefront runs on: XCC_ID, and shader engine / array / CU of HW_ID; never 0.
+__device__ __forceinline__ unsigned this_cu()
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    return 0x10000u | ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
+}
+
 template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
@@ -428,7 +435,23 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #if OALSFX_CHAIN_EXP & 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below behind the wait)
+        // Which CU did the launch before run this instance on?  Its wavefront kept reading the instance's lines while this launch was
+        // already on the chip (that is the overlap), after this launch's start had emptied the L1s, and wrote some of them afterwards
+        // (an all-pass ring comes round within a call or two).  Stores do not refresh an L1 copy of uncached memory: on that CU -- and on
+        // no other -- the L1 may hold lines of this instance as they were.  Found with 70 instances, whose workgroups land on the same
+        // CUs launch after launch (tests/test_gpu_chained.py::test_property_changes_inside_a_run).  So: the same CU, and only then, an
+        // agent-scope acquire (buffer_inv sc1: this CU's L1 dropped); a full chip hands most instances to another CU.
+        {
+            unsigned before_cu = 0;
+            if (valid && lane == 0) before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before_cu = __builtin_amdgcn_readfirstlane(before_cu);
+            if (before_cu == this_cu()) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below behind the wait)
+            }
+        }
 #endif
         __builtin_amdgcn_s_dcache_inv();
         __builtin_amdgcn_s_waitcnt(0);
@@ -456,7 +479,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if constexpr (FP) {
         // ---- the hot record: 1 KiB, one 16-byte load per lane, straight into the LDS tables ----
         const v4u* rec = reinterpret_cast<const v4u*>(ctx.hot + sidx * hot::SIZE);
+#if OALSFX_CHAIN_EXP & 16
+        v4u r;
+        {
+            const unsigned long long* r8 = reinterpret_cast<const unsigned long long*>(rec + lane);
+            const unsigned long long a = __hip_atomic_load(r8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c = __hip_atomic_load(r8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.x = static_cast<unsigned>(a); r.y = static_cast<unsigned>(a >> 32); r.z = static_cast<unsigned>(c); r.w = static_cast<unsigned>(c >> 32);
+        }
+#else
         const v4u r = rec[lane];
+#endif
         // the first tile's frame does not depend on the record (unless the send-filter pre-pass ran): it travels beside it
         if (!(flags & kFiltered)) {
             const float* raw = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
@@ -1575,6 +1607,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if (ctx.turn != nullptr && ctx.turn_set != 0u) {
         // this launch is through with the instance (its stores acknowledged): the next one may take it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (valid && lane == 0) __hip_atomic_store(ctx.turn_cu + sidx, this_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (where: see the wait)
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
         if (valid && lane == 0) __hip_atomic_store(ctx.turn + sidx, ctx.turn_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

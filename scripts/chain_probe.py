@@ -20,4 +20,5 @@ for rep in range(3):
     for k in range(calls): b.mix_device(frames, src.data_ptr(), dst.data_ptr())
     b.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{n} x {frames}: step {dt / calls * 1e6:7.2f} us, {b.chained_calls - before} of {calls} calls chained", flush=True)
+    same = b._lib.oalsfx_debug_chain_same_cu(b._h)
+    print(f"{n} x {frames}: step {dt / calls * 1e6:7.2f} us, {b.chained_calls - before} of {calls} calls chained; hand-overs on one CU so far: {same} of {b.chained_calls * n}", flush=True)
