@@ -47,6 +47,14 @@ constexpr int kSideStreams = 3; // ring-light effects, proven-steady reverbs, be
 
 } // namespace
 
+// How many launches of a run of chained launches may be in flight (streams taken in turn).  Two overlap one launch's tail with the next
+// one's head; a third keeps the workgroup slots that fast workgroups free in use while the slowest of the launch two before are still
+// at work (cross-fading instances, presets of the slower kinds): a launch starts when the launch kChainDepth before it has completed.
+#ifndef OALSFX_CHAIN_DEPTH
+#define OALSFX_CHAIN_DEPTH 3
+#endif
+constexpr int kChainDepth = OALSFX_CHAIN_DEPTH;
+
 struct oalsfx_batch {
     int n = 0, slots = 0, channels = 0, rate = 0, device = 0;
     int format = 0;
@@ -107,7 +115,7 @@ struct oalsfx_batch {
     size_t filtered_capacity = 0;                 // floats per send plane
     float* d_mixbuf = nullptr;
     int* d_lists = nullptr;                       // [slots][n]: the one of d_lists_buf the next launches read
-    int* d_lists_buf[2] = {};                     // every rebuilt list goes to the other buffer: a launch that is still in flight -- chained
+    int* d_lists_buf[kChainDepth + 1] = {};       // every rebuilt list goes to the next buffer: a launch that is still in flight -- chained
                                                   // launches -- keeps reading the list it was given
     int lists_turn = 0;
     int* d_progress = nullptr;                    // [n*slots] hand-off from the steady-state reverb kernel to the general kernel behind it
@@ -116,6 +124,7 @@ struct oalsfx_batch {
     unsigned* d_exact = nullptr;                  // [n*slots] "settled and at rest" as the reverb kernels left it
     unsigned* h_exact = nullptr;                  // pinned copy of d_exact, filled by the read-back
     char fault_text[200] = {};
+    long long host_prepare_ns = 0, host_stage_wait_ns = 0, host_derive_ns = 0, host_lists_ns = 0; // OALSFX_HOST_PROFILE: where the host's time inside mix_device goes
     unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
     unsigned* d_fault = nullptr;                  // device address of h_fault
     hipEvent_t ev_exact = nullptr;
@@ -172,8 +181,10 @@ struct oalsfx_batch {
     // streams with nothing but a word per instance ordering them (KernelCtx::turn), so that the tail of one launch overlaps with the head
     // of the next (the ~6 us between dependent launches of one stream).  Off once the caller has asked for the stream handle: work
     // queued there by the caller expects the launches in stream order.
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_chain = nullptr;
+    hipStream_t chain_stream[kChainDepth] = {};   // [0] is `stream`; a run's launches take them in turn
+    hipEvent_t ev_chain[kChainDepth] = {};
+    int chain_pos = 0;                            // the stream of the last chained launch
+    bool chain_used[kChainDepth] = {};            // streams the current run has launched on
     hipEvent_t ev_chain_start = nullptr;          // recorded in front of a run's first launch: the second (other stream) starts no earlier
     unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups of chained launches that have started (k_chain_gate)
     uint32_t turn_counter = 0;                    // the number the last chained launch set
@@ -183,7 +194,6 @@ struct oalsfx_batch {
     int resident_groups = 0;                      // workgroups of a steady-state reverb launch the device holds at once (4 per CU)
     bool uncached = false;                        // what launches hand on lives in uncached memory: calls can be chained launches
     bool chain_open = false;                      // the last call was a chained launch (its kernel may still run, on either stream)
-    bool chain_on_second = false;                 // ... on stream2
     bool stream_handed_out = false;
     long long chained_calls = 0;
     // the kernel groups of one slot (ring-light effects, reverb, EAX reverb) touch disjoint instances: when more than one
@@ -526,7 +536,9 @@ oalsfx_batch::Stage* acquire_stage(oalsfx_batch* b, size_t bytes)
     }
     if (pick < 0) {
         pick = b->stage_turn;
+        const auto w0 = std::chrono::steady_clock::now();
         if (!b->hip_ok(hipEventSynchronize(b->stage[pick].done), "hipEventSynchronize")) return nullptr;
+        b->host_stage_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
     }
     oalsfx_batch::Stage& st = b->stage[pick];
     b->stage_turn = (pick + 1) & 3;
@@ -580,6 +592,7 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
         if (!b->hip_ok(hipStreamWaitEvent(b->stream, b->ev_mixed, 0), "hipStreamWaitEvent")) return false;
     }
 
+    const auto hd0 = std::chrono::steady_clock::now();
     for (int i : b->dirty_list) {
         InstanceHost& h = b->inst[i];
         bool updated = false, sends_moved = false;
@@ -659,6 +672,7 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
         b->inst_dirty[i] = 0;
     }
     b->dirty_list.clear();
+    b->host_derive_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hd0).count();
 
     // slots that start over take and give back delay lines, which launches of a run of chained launches may still be at work on
     if (!restarted.empty() && !chain_join(b)) return false;
@@ -706,6 +720,7 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
 
     // ---- the launch plan: one counting sort over the slots of every instance ----
     const bool rebuild_lists = any_type_change || b->lists_dirty;
+    const auto hl0 = std::chrono::steady_clock::now();
     std::vector<int> lists;
     if (rebuild_lists) {
         lists.resize(total);
@@ -761,6 +776,7 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
         b->lists_version += 1;
     }
 
+    b->host_lists_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hl0).count();
     // ---- one packed upload: [indices | records] per array, the ring table, the lists ----
     auto padded = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     const size_t n_p = up_params.size(), n_s = up_state.size(), n_src = up_source.size(), n_t = up_touched.size();
@@ -797,7 +813,7 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
         // one launch puts everything in place
         auto words = [&](size_t o) { return reinterpret_cast<const unsigned*>(from + o); };
         auto ints = [&](size_t o) { return reinterpret_cast<const int*>(from + o); };
-        if (rebuild_lists) b->d_lists = b->d_lists_buf[b->lists_turn ^= 1]; // (launches in flight keep the list they were given)
+        if (rebuild_lists) b->d_lists = b->d_lists_buf[b->lists_turn = (b->lists_turn + 1) % (kChainDepth + 1)]; // (launches in flight keep the list they were given)
         oalsfx_hip::UploadJobs& jobs = pu.jobs;
         jobs = oalsfx_hip::UploadJobs{};
         // (slot parameters and epochs take their turn instance by instance when the upload runs beside the launch before it)
@@ -1152,8 +1168,13 @@ bool chain_join(oalsfx_batch* b)
 {
     if (!b->chain_open) return true;
     b->chain_open = false;
-    if (!b->chain_on_second) return true;
-    return b->hip_ok(hipEventRecord(b->ev_chain, b->stream2), "hipEventRecord") && b->hip_ok(hipStreamWaitEvent(b->stream, b->ev_chain, 0), "hipStreamWaitEvent");
+    for (int k = 1; k < kChainDepth; ++k) {
+        if (!b->chain_used[k]) continue;
+        b->chain_used[k] = false;
+        if (!b->hip_ok(hipEventRecord(b->ev_chain[k], b->chain_stream[k]), "hipEventRecord") ||
+            !b->hip_ok(hipStreamWaitEvent(b->stream, b->ev_chain[k], 0), "hipStreamWaitEvent")) return false;
+    }
+    return true;
 }
 
 // Can this call be a chained launch?  The batch's own stream, nobody holding its handle, nothing to upload, no per-launch events, one
@@ -1203,14 +1224,17 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     // what has changed since the last call: the host's part first (it decides what this call launches), the upload itself below, where
     // the call's launches go
     PendingUpload upload;
+    const auto hp0 = std::chrono::steady_clock::now();
     if (!prepare_params(b, upload)) return false;
+    b->host_prepare_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hp0).count();
     const bool chained = may_chain && (!upload.st || upload.chainable) && chain_eligible(b, frames, src, dst, stream);
     if (!chained && !chain_join(b)) return false;
     hipStream_t const caller_stream = stream;
     if (chained) {
         // take turns on the two streams; the first of a run stays on the batch's stream, behind whatever was queued there before
-        b->chain_on_second = b->chain_open && !b->chain_on_second;
-        stream = b->chain_on_second ? b->stream2 : b->stream;
+        b->chain_pos = b->chain_open ? (b->chain_pos + 1) % kChainDepth : 0;
+        stream = b->chain_stream[b->chain_pos];
+        b->chain_used[b->chain_pos] = true;
     }
     (void)caller_stream;
     if (!chained && !launch_params(b, upload, b->stream, stream)) return false;
@@ -1267,12 +1291,15 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
             b->chain_len = 1;
         } else {
-            // (the second of a run is the first on the other stream: not before the first could start either)
-            if (b->chain_len++ == 1 && !b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
+            // (the first launch of the run on one of the other streams: not before the run's first could start either)
+            if (b->chain_len++ < kChainDepth && !b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
             // (0x800: the gate in front of a run's second launch only, as first built -- the negative control of
             // tests/test_gpu_chained.py::test_the_first_run_of_a_fresh_process)
-            if (b->chain_len == 2 || !(debug_flags() & 0x800))
-                oalsfx_hip::launch_chain_gate(started, b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1)), b->d_fault, stream);
+            if (b->chain_len == 2 || !(debug_flags() & 0x800)) {
+                const unsigned target = b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1));
+                if (upload.st) { upload.jobs.gate_started = started; upload.jobs.gate_target = target; } // (the upload kernel is the gate as well)
+                else oalsfx_hip::launch_chain_gate(started, target, b->d_fault, stream);
+            }
         }
         ctx.turn_started = started;
         b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
@@ -1472,7 +1499,11 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     mark_touched(b, 0, n_instances);
 
     bool ok = b->hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
-    ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking), "hipStreamCreate");
+    b->chain_stream[0] = b->stream;
+    for (int k = 1; k < kChainDepth; ++k) {
+        ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->chain_stream[k], hipStreamNonBlocking), "hipStreamCreate");
+        ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain[k], hipEventDisableTiming), "hipEventCreate");
+    }
     {
         // every steady-state build is held to four workgroups per CU (registers, LDS: tests/test_kernel_resources.py)
         int cus = 0;
@@ -1486,7 +1517,6 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
         b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances & 3) == 0 && n_instances / 4 <= b->resident_groups &&
                       (!kind || std::strcmp(kind, "uncached") == 0);
     }
-    ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
     for (int k = 0; k < kSideStreams; ++k) {
         ok = ok && b->hip_ok(hipStreamCreateWithFlags(&b->side_stream[k], hipStreamNonBlocking), "hipStreamCreate");
@@ -1500,8 +1530,11 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_source), n_instances * sizeof(oalsfx_source_params)), "hipMalloc(source)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_rings), total * sizeof(float*)), "hipMalloc(ring table)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_source_state), n_instances * sizeof(oalsfx_source_state)), "hipMalloc(source state)");
-    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists_buf[0]), 2 * total * sizeof(int)), "hipMalloc(lists)");
-    if (ok) { b->d_lists_buf[1] = b->d_lists_buf[0] + total; b->d_lists = b->d_lists_buf[0]; }
+    ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_lists_buf[0]), (kChainDepth + 1) * total * sizeof(int)), "hipMalloc(lists)");
+    if (ok) {
+        for (int k = 1; k <= kChainDepth; ++k) b->d_lists_buf[k] = b->d_lists_buf[0] + k * total;
+        b->d_lists = b->d_lists_buf[0];
+    }
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_progress), total * sizeof(int)), "hipMalloc(progress)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_progress, 0, total * sizeof(int), b->stream), "hipMemsetAsync(progress)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_hot), total * oalsfx_hip::hot::SIZE * sizeof(unsigned)), "hipMalloc(hot records)");
@@ -1535,7 +1568,8 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
 {
     if (!b) return;
     hipSetDevice(b->device);
-    if (b->stream2) hipStreamSynchronize(b->stream2);
+    for (int k = 1; k < kChainDepth; ++k)
+        if (b->chain_stream[k]) hipStreamSynchronize(b->chain_stream[k]);
     if (b->stream) hipStreamSynchronize(b->stream);
     for (int k = 0; k < kSideStreams; ++k)
         if (b->side_stream[k]) hipStreamSynchronize(b->side_stream[k]);
@@ -1549,13 +1583,18 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
     }
     for (auto& t : b->timed) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (hipEvent_t e : b->event_pool) hipEventDestroy(e);
+    if (std::getenv("OALSFX_HOST_PROFILE"))
+        std::fprintf(stderr, "host profile: prepare_params %.1f ms (of which waiting for a staging buffer %.1f ms), %lld mix_device calls chained\n",
+                     b->host_prepare_ns * 1e-6, b->host_stage_wait_ns * 1e-6, b->chained_calls);
     for (void* c : b->chunks) handed_on_free(c);
     hipFree(b->d_params); handed_on_free(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); handed_on_free(b->d_source_state); hipFree(b->d_filtered);
     hipFree(b->d_mixbuf); hipFree(b->d_lists_buf[0]); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     handed_on_free(b->d_hot); hipFree(b->d_inst_epoch); handed_on_free(b->d_exact); handed_on_free(b->d_turn);
-    if (b->ev_chain) hipEventDestroy(b->ev_chain);
+    for (int k = 1; k < kChainDepth; ++k)
+        if (b->ev_chain[k]) hipEventDestroy(b->ev_chain[k]);
     if (b->ev_chain_start) hipEventDestroy(b->ev_chain_start);
-    if (b->stream2) hipStreamDestroy(b->stream2);
+    for (int k = 1; k < kChainDepth; ++k)
+        if (b->chain_stream[k]) hipStreamDestroy(b->chain_stream[k]);
     if (b->h2d_stream) hipStreamSynchronize(b->h2d_stream);
     if (b->d2h_stream) hipStreamSynchronize(b->d2h_stream);
     for (auto& ps : b->pipe) {
@@ -1832,6 +1871,11 @@ int oalsfx_batch_synchronize(oalsfx_batch* b)
 {
     if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b)) return 0;
     if (!b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    if (std::getenv("OALSFX_HOST_PROFILE")) {
+        std::fprintf(stderr, "host profile since the last synchronize: prepare_params %.1f us, of which staging-buffer waits %.1f us, derive %.1f us, lists %.1f us; %lld calls chained so far\n",
+                     b->host_prepare_ns * 1e-3, b->host_stage_wait_ns * 1e-3, b->host_derive_ns * 1e-3, b->host_lists_ns * 1e-3, b->chained_calls);
+        b->host_prepare_ns = b->host_stage_wait_ns = b->host_derive_ns = b->host_lists_ns = 0;
+    }
     poll_exact(b);
     return check_fault(b) ? 1 : 0;
 }

@@ -167,7 +167,9 @@ struct ScatterJob { unsigned* dst; const unsigned* packed; const int* indices; i
 struct CopyJob { unsigned* dst; const unsigned* src; size_t dwords; int blocks; };
 // turn / turn_wait / fault (chained launches, batch.cpp): a record of a job that takes turns is stored once the launch before is through
 // with the instance it belongs to (the word turn[indices[k]] holds turn_wait); nullptr / 0: at once
-struct UploadJobs { ScatterJob scatter[4]; CopyJob copy[2]; const unsigned* turn; unsigned turn_wait; unsigned* fault; };
+// gate_started / gate_target: the upload doubles as the gate of the chained launch behind it (k_chain_gate): its first workgroup also
+// waits until *gate_started has reached gate_target
+struct UploadJobs { ScatterJob scatter[4]; CopyJob copy[2]; const unsigned* turn; unsigned turn_wait; unsigned* fault; const unsigned* gate_started; unsigned gate_target; };
 void launch_upload(UploadJobs jobs, hipStream_t stream);
 void launch_null(hipStream_t stream);
 // dst[0 .. floats) = src[0 .. floats), either of them possibly page-locked host memory mapped into the device's address space

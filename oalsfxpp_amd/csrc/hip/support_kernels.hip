@@ -257,9 +257,8 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
 // Chained launches (batch.cpp): a launch whose workgroups wait for the launch before must not take the chip before that
 // launch has its workgroups on it; every chained launch but a run's first comes behind this gate.  (In the steady state of a run it
 // finds its count reached: the launch before has been taking over the places of the launch two before, which has just completed.)
-__global__ __launch_bounds__(64) void k_chain_gate(const unsigned* started, unsigned target, unsigned* fault)
+__device__ __forceinline__ void chain_gate_wait(const unsigned* started, unsigned target, unsigned* fault)
 {
-    if (threadIdx.x != 0) return;
     unsigned spins = 0;
     while (static_cast<int>(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(8);
@@ -268,6 +267,11 @@ __global__ __launch_bounds__(64) void k_chain_gate(const unsigned* started, unsi
             break;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void k_chain_gate(const unsigned* started, unsigned target, unsigned* fault)
+{
+    if (threadIdx.x == 0) chain_gate_wait(started, target, fault);
 }
 
 void launch_chain_gate(const unsigned* started, unsigned target, unsigned* fault, hipStream_t stream)
@@ -329,6 +333,8 @@ __global__ __launch_bounds__(256) void k_upload(UploadJobs jobs)
 {
     int k = blockIdx.x;
     const int t = threadIdx.x;
+    // (the gate of the chained launch behind this upload: one wavefront's worth of waiting, beside the work of the others)
+    if (blockIdx.x == 0 && t == 255 && jobs.gate_started != nullptr) chain_gate_wait(jobs.gate_started, jobs.gate_target, jobs.fault);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const ScatterJob& sj = jobs.scatter[j];

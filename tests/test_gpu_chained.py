@@ -13,7 +13,10 @@ from oalsfxpp_amd import desc, lib
 from oalsfxpp_amd.api import Batch
 from oracle import oracle as orc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(__import__("os").environ.get("OALSFX_RING_MEMORY", "uncached") != "uncached" or
+                                 int(__import__("os").environ.get("OALSFX_DEBUG_FLAGS", "0"), 0) & 0x400 != 0,
+                                 reason="chained launches are switched off in this environment")]
 
 E = make_effect
 
