@@ -50,3 +50,10 @@ bash scripts/pmc_configs.sh $N/pmc_configs > /dev/null 2>&1 || true
 bash scripts/pmc_types.sh > /dev/null 2>&1 && cp $R/gpurun_out/pmc_types/per_type_counters.txt $O/per_effect_type_counters.txt || true
 bash scripts/pmc_mem.sh $N/pmc_mem > /dev/null 2>&1 || true
 echo "round 3 additions done" >> $O/progress.txt
+# late round 3: chained launches
+bash scripts/chained_evidence.sh $N/chained > /dev/null 2>&1 || true
+bash scripts/uncached_memory_bench.sh > $O/chained/uncached_memory.txt 2>&1 || true
+bash scripts/storm_kernels.sh $N/chained/storm4 4 > /dev/null 2>&1 && cp $O/chained/storm4/storm_kernel_timeline.txt $O/chained/storm4_chained_timeline.txt || true
+OALSFX_DEBUG_FLAGS=0x400 python3 scripts/update_storm_bench.py 2>/dev/null | grep updates > $O/update_storm_in_stream_order.txt || true
+python3 bench.py --no-chain --no-cpu-baseline --host-io 0 2>/dev/null | tail -1 > $O/bench_default_no_chain.json || true
+echo "chained launches done" >> $O/progress.txt
