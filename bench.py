@@ -151,6 +151,7 @@ def percentile(sorted_values, q):
 
 ROOFLINE_WARMUP = 64       # the fixed internal region the roofline object is measured on, whatever --steps / --warmup say
 ROOFLINE_LAUNCHES = 128
+CHAINED_RUN = 512          # launches of the steady-state measurement of chained launches (roofline.chained_launches)
 
 
 def device_record(rank, ordinal):
@@ -277,6 +278,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="experiment: no HIP events around the launches (roofline fields then use the step time)")
     ap.add_argument("--preset-mix", action="store_true", help="robustness run: instance i uses EFX preset i %% 113")
+    ap.add_argument("--spin-up-ms", type=float, default=60.0, help="untimed steps of the workload for this long before the warm-up steps, so "
+                    "that the card has reached its clocks when the short timed region starts (0: off)")
     ap.add_argument("--no-chain", action="store_true", help="consecutive calls in plain stream order (no overlap of a launch's tail with the "
                     "next one's head): the configuration whose rocprofv3 kernel durations are those of the kernel alone")
     ap.add_argument("--preset", type=int, default=-1, help="experiment: every instance uses EFX preset N")
@@ -349,6 +352,18 @@ def main():
 
     n_in = 8
     src, dst = resident_inputs(batch, n, rank, n_in)
+    # The card takes tens of milliseconds of continuous load to reach its clocks (the same loop runs 45 us per step for its first 16 ms and
+    # 39 afterwards, chained or not: scripts/chain_probe.py), and --steps 20 --warmup 5 is one millisecond: the device is brought up to
+    # speed first, with the workload's own steps, untimed, before the W warm-up steps the command line asks for.  (--spin-up-ms 0: off.)
+    if args.spin_up_ms > 0:
+        for k in range(2):
+            batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+            batch.synchronize()
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spin_up_ms * 1e-3:
+            for k in range(64):
+                batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+            batch.synchronize()
     for k in range(args.warmup):
         batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
         if k < 2:
@@ -438,6 +453,7 @@ def main():
         "config": {
             "workload": (WORKLOADS["config5"] if config5_main else WORKLOADS[workload]).format(n=n),
             "instances_per_gpu": n,
+            "device_spin_up_ms": args.spin_up_ms,
             "frames_per_buffer": FRAMES,
             "parallelism": f"batch-split x{world}, no collectives",
             "devices": devices,
@@ -453,6 +469,23 @@ def main():
         "calls_chained_in_timed_region": chained, "of": args.steps, "step_us": round(elapsed / args.steps * 1e6, 2),
         "achieved_over_step": round(step_gbs, 1), "frac_over_step": round(step_gbs / HBM_PEAK_GBS, 4),
         "note": "algorithmic bytes of a step / step time of the CLI-timed region (launch gaps included); --no-chain runs the region in plain stream order"}
+    if workload == "config2" and not args.no_kernel_timing and not args.no_chain:
+        # ... and in the steady state of a long run: CHAINED_RUN launches without a synchronisation, the time between the first's start and
+        # the last's end on the host's clock over the launches (a launch ends every so often; each takes about twice that from start to end)
+        for k in range(ROOFLINE_WARMUP):
+            batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+        batch.synchronize()
+        c0 = batch.chained_calls
+        t0 = time.perf_counter()
+        for k in range(CHAINED_RUN):
+            batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+        batch.synchronize()
+        interval = (time.perf_counter() - t0) / CHAINED_RUN
+        run_gbs = bytes_per_step / interval / 1e9
+        result["roofline"]["chained_launches"].update({
+            "steady_state_interval_us": round(interval * 1e6, 2), "steady_state_launches": CHAINED_RUN,
+            "steady_state_calls_chained": batch.chained_calls - c0, "achieved_steady_state": round(run_gbs, 1),
+            "frac_steady_state": round(run_gbs / HBM_PEAK_GBS, 4)})
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file) and workload == "config2" and n == 4096 and not args.no_kernel_timing:
         with open(traffic_file) as f:
