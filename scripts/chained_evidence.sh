@@ -3,6 +3,7 @@ N=$1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$N; mkdir -p $O
 cd $R
 bash scripts/bench20.sh > $O/bench_steps20_warmup5.txt 2>/dev/null
+bash scripts/bench20_spin.sh > $O/bench20_spin_up.txt 2>/dev/null
 bash scripts/chain_trace.sh $N/trace_chained > /dev/null 2>&1 && cp $O/trace_chained/timeline.txt $O/timeline_chained.txt && cp $O/trace_chained/probe.log $O/probe_chained.txt
 OALSFX_DEBUG_FLAGS=0x400 bash scripts/chain_trace.sh $N/trace_stream_order > /dev/null 2>&1 && cp $O/trace_stream_order/timeline.txt $O/timeline_stream_order.txt && cp $O/trace_stream_order/probe.log $O/probe_stream_order.txt
 for f in 64 128 256 512 1024 2048; do
