@@ -137,7 +137,7 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 // Measured (scripts/ab_libs.py, profiles/r03g_aligned_windows/): 256-frame calls 43.9 -> 42.3 us (-3.5 %), 512-frame calls -8.5 %,
 // 2048-frame calls 333.8 -> 297.6 us (-10.9 %: 37.2 us per 256 frames, 0.73 of the roofline).
 #ifndef OALSFX_CHAIN_EXP
-#define OALSFX_CHAIN_EXP 0 // experiments: 1 an agent-scope acquire behind the wait for a turn, 2 plain stores of the output frames (timing only),
+#define OALSFX_CHAIN_EXP 0 // experiments: 1 an agent-scope acquire behind every wait for a turn, 2 plain stores of the output frames (timing only),
                            // 8 no wait at all (negative control of tests/test_gpu_chained.py: it must fail)
 #endif
 #ifndef OALSFX_AW
@@ -414,10 +414,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     //    stores are acknowledged (s_waitcnt vmcnt(0), then the word).  (Agent-scope fences over cached memory -- a write-back of the L2
     //    per wavefront -- were measured first: 245 us per step instead of 50.)
     //  - No cache line holds bytes of two instances (SlotStateLines, common.hpp), and nobody but this wavefront reads the instance's
-    //    lines in this launch: this CU's vector L1, emptied when the launch started, holds none of them before the wait is over, and
-    //    needs no invalidate behind it (an agent-scope acquire there -- buffer_inv sc1 -- cost 9 us per step, more than the overlap
-    //    gains; profiles/r03k_chained_launches).  The scalar cache is another matter: it is not written through by vector stores, so a
-    //    line the launch before loaded through it may still be there; s_dcache_inv costs nothing measurable.
+    //    lines in this launch (chained launches are grids of whole workgroups: the idle wavefronts of an incomplete one would run beside
+    //    the first instance of their kind's list and read its records without waiting -- batch.cpp): this CU's vector L1, emptied when
+    //    the launch started, holds none of them before the wait is over, and needs no invalidate behind it (an agent-scope acquire there
+    //    -- buffer_inv sc1 -- cost 9 to 12 us per step, more than the overlap gains; profiles/r03k_chained_launches).  The scalar cache
+    //    is another matter: it is not written through by vector stores, so a line the launch before loaded through it may still be
+    //    there; s_dcache_inv costs nothing measurable.
     //  - The wait ends: the launch before has its workgroups on the chip before this one gets its first (batch.cpp, k_chain_gate), and
     //    a count-out reports through the fault word rather than hang.
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -435,12 +437,12 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #if OALSFX_CHAIN_EXP & 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
-        // Which CU did the launch before run this instance on?  Its wavefront kept reading the instance's lines while this launch was
-        // already on the chip (that is the overlap), after this launch's start had emptied the L1s, and wrote some of them afterwards
-        // (an all-pass ring comes round within a call or two).  Stores do not refresh an L1 copy of uncached memory: on that CU -- and on
-        // no other -- the L1 may hold lines of this instance as they were.  Found with 70 instances, whose workgroups land on the same
-        // CUs launch after launch (tests/test_gpu_chained.py::test_property_changes_inside_a_run).  So: the same CU, and only then, an
-        // agent-scope acquire (buffer_inv sc1: this CU's L1 dropped); a full chip hands most instances to another CU.
+        // One reader of the instance's lines is left that this launch's start did not come after: the instance's own wavefront of the
+        // launch before, which kept reading them while this launch was already on the chip (that is the overlap) and wrote some of them
+        // afterwards (an all-pass ring comes round within a call or two).  Whether a CU's L1 keeps such a line as it was read is not
+        // something this code relies on: where the hand-over stays on one CU -- the launch before leaves the CU's name beside the word --
+        // this wavefront does pay for the agent-scope acquire.  It does not happen in practice (0 of 4.9 million hand-overs,
+        // scripts/chain_probe.py): a workgroup is on the chip, waiting, before the one it waits for leaves its CU.
         {
             unsigned before_cu = 0;
             if (valid && lane == 0) before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -479,16 +481,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if constexpr (FP) {
         // ---- the hot record: 1 KiB, one 16-byte load per lane, straight into the LDS tables ----
         const v4u* rec = reinterpret_cast<const v4u*>(ctx.hot + sidx * hot::SIZE);
-#if OALSFX_CHAIN_EXP & 16
-        v4u r;
-        {
-            const unsigned long long* r8 = reinterpret_cast<const unsigned long long*>(rec + lane);
-            const unsigned long long a = __hip_atomic_load(r8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c = __hip_atomic_load(r8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r.x = static_cast<unsigned>(a); r.y = static_cast<unsigned>(a >> 32); r.z = static_cast<unsigned>(c); r.w = static_cast<unsigned>(c >> 32);
-        }
-#else
         const v4u r = rec[lane];
-#endif
         // the first tile's frame does not depend on the record (unless the send-filter pre-pass ran): it travels beside it
         if (!(flags & kFiltered)) {
             const float* raw = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;

@@ -19,8 +19,8 @@ with open(O + "/timeline.txt", "w") as out:
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
         out.write(f"{s:9.1f} {e:9.1f} {e - s:7.1f} {'' if ps is None else f'{s - ps:7.1f}':>7} {'' if pe is None else f'{e - pe:7.1f}':>7}  q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:60]}\n")
         ps, pe = s, e
-    ends = [int(r["End_Timestamp"]) for r in rows[-200:]]
-    out.write(f"end-to-end interval over the last {len(ends)} launches: {(ends[-1] - ends[0]) / 1e3 / (len(ends) - 1):.2f} us\n")
+    ends = [int(r["End_Timestamp"]) for r in rows if "steady" in r["Kernel_Name"]][-200:]
+    out.write(f"end-to-end interval over the last {len(ends)} reverb launches: {(ends[-1] - ends[0]) / 1e3 / (len(ends) - 1):.2f} us\n")
 print(open(O + "/timeline.txt").read())
 os.remove(f)
 PY

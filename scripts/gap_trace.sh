@@ -1,8 +1,8 @@
-# Gaps between consecutive kernels of the headline loop: rocprofv3 --kernel-trace of bench.py (run through gpurun): bash scripts/gap_trace.sh <out-dir-under-gpurun_out> [bench args]
+# Gaps between consecutive kernels of the headline loop in plain stream order (--no-chain; chained launches overlap: scripts/chain_trace.sh): rocprofv3 --kernel-trace of bench.py (run through gpurun): bash scripts/gap_trace.sh <out-dir-under-gpurun_out> [bench args]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; shift
 mkdir -p $O; cd $R
-OALSFX_TRAFFIC_REFRESH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o g -- python3 bench.py --steps 200 --warmup 64 --no-cpu-baseline --host-io 0 "$@" > $O/bench.log 2>&1
+OALSFX_TRAFFIC_REFRESH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o g -- python3 bench.py --steps 200 --warmup 64 --no-cpu-baseline --host-io 0 --no-chain "$@" > $O/bench.log 2>&1
 O=$O python3 - <<'PY'
 import csv, glob, os, re
 O = os.environ["O"]
