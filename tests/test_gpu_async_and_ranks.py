@@ -104,7 +104,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OALSFX_DIST_BACKEND="gloo", OALSFX_DUMP_OUTPUT=str(tmp_path / f"rank{rank}_dst.npy"))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "8",
-                                       "--no-cpu-baseline", "--instances", "64"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                       "--no-cpu-baseline", "--instances", "64", "--spin-up-ms", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
@@ -132,7 +132,10 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
                     tmp.synchronize()
                     src[k][r * 64 * 512:(r + 1) * 64 * 512] = part
         torch.cuda.synchronize()
-        steps = 8 + 8 + 32 + 64 + 128   # warm-up, timed region, kernel statistics (bench.KERNEL_STATS_STEPS), the fixed roofline region (bench.ROOFLINE_WARMUP + ROOFLINE_LAUNCHES)
+        # warm-up, timed region, kernel statistics (bench.KERNEL_STATS_STEPS), the fixed roofline region (bench.ROOFLINE_WARMUP +
+        # ROOFLINE_LAUNCHES), the steady state of chained launches (ROOFLINE_WARMUP + CHAINED_RUN; 64 instances are whole workgroups).  No
+        # device spin-up (--spin-up-ms 0): it runs for a time, not for a number of steps.
+        steps = 8 + 8 + 32 + 64 + 128 + 64 + 512
         for k in range(steps):
             b.mix_device(256, src[k % 8].data_ptr(), dst.data_ptr())
         b.synchronize()
@@ -146,7 +149,7 @@ def test_bench_gpus_2_without_a_launcher(tmp_path):
     or HIP) and relays rank 0's line; it never benchmarks one GPU under a --gpus 2 label.  gloo between the ranks because both share
     the one GPU here; with the default backend the same command must refuse instead."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6", "--no-cpu-baseline", "--instances", "64",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6", "--no-cpu-baseline", "--instances", "64", "--spin-up-ms", "0",
            "--no-config5"]
     r = subprocess.run(cmd, env=dict(env, OALSFX_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
