@@ -880,7 +880,10 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // caller's stream takes a slot's first part instead of its general kernel, 0x40000000 no cross-fading build: reverbs whose properties
 // change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
 // general path inside (experiment: what the fallback's scratch frame costs the grid), 0x200 no send filters inside the steady-state
-// builds (the pre-pass kernel for every filtered instance, as before round 3)
+// builds (the pre-pass kernel for every filtered instance, as before round 3), 0x400 no chained launches: consecutive calls in plain
+// stream order (bench.py --no-chain), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
+// of tests/test_gpu_chained.py: it must fail).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
+// delay lines, state and hot records live), OALSFX_HOST_PROFILE (what the host spends in prepare_params, printed by synchronize)
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
 {
