@@ -55,6 +55,9 @@ int oalsfx_batch_effect_count(const oalsfx_batch* b);           /* Api::get_effe
 /* Api::set_effect (src/oalsfxpp.cpp:3639-3658; this ABI reports success as 1, the C++ facade keeps
  * the reference's quirk of returning false). */
 int oalsfx_batch_set_effect(oalsfx_batch* b, int first, int count, int slot, const oalsfx_effect* effects, int stride_bytes);
+/* The same for instances that are not neighbours: instances[k] gets effects[k] (stride_bytes apart; 0: one effect for all).  One call
+ * where a loop over oalsfx_batch_set_effect would make one per instance -- a foreign-function call costs more than the setter. */
+int oalsfx_batch_set_effect_at(oalsfx_batch* b, const int* instances, int count, int slot, const oalsfx_effect* effects, int stride_bytes);
 /* Api::set_effect_type (src/oalsfxpp.cpp:3597-3616): type tag + that type's default properties. */
 int oalsfx_batch_set_effect_type(oalsfx_batch* b, int first, int count, int slot, int effect_type);
 /* Api::set_effect_props (src/oalsfxpp.cpp:3618-3637): replaces the 108-byte union only. */

@@ -67,6 +67,15 @@ class Batch:
             arr = (desc.Effect * count)(*effect)
             self._check(self._lib.oalsfx_batch_set_effect(self._h, first, count, slot, arr, C.sizeof(desc.Effect)))
 
+    def set_effect_at(self, slot, instances, effects):
+        """`effects[k]` (or the one `desc.Effect`) for instance `instances[k]`: one foreign call for instances that are not neighbours."""
+        idx = (C.c_int * len(instances))(*instances)
+        if isinstance(effects, desc.Effect):
+            self._check(self._lib.oalsfx_batch_set_effect_at(self._h, idx, len(instances), slot, C.byref(effects), 0))
+        else:
+            arr = (desc.Effect * len(instances))(*effects)
+            self._check(self._lib.oalsfx_batch_set_effect_at(self._h, idx, len(instances), slot, arr, C.sizeof(desc.Effect)))
+
     def set_effect_type(self, slot, effect_type, first=0, count=None):
         first, count = self._range(first, count)
         self._check(self._lib.oalsfx_batch_set_effect_type(self._h, first, count, slot, effect_type))

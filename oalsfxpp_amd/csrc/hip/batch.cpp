@@ -1651,6 +1651,20 @@ int oalsfx_batch_set_effect(oalsfx_batch* b, int first, int count, int slot, con
     return 1;
 }
 
+int oalsfx_batch_set_effect_at(oalsfx_batch* b, const int* instances, int count, int slot, const oalsfx_effect* effects, int stride_bytes)
+{
+    if (count < 0 || (count > 0 && (!instances || !effects))) return b->fail(kErrRange) ? 1 : 0;
+    if (slot < 0 || slot >= b->slots) return b->fail(kErrSlot) ? 1 : 0;
+    for (int k = 0; k < count; ++k)
+        if (instances[k] < 0 || instances[k] >= b->n) return b->fail(kErrRange) ? 1 : 0; // (nothing is set when one index is out of range)
+    const auto* base = reinterpret_cast<const unsigned char*>(effects);
+    for (int k = 0; k < count; ++k) {
+        std::memcpy(&b->inst[instances[k]].deferred[slot], base + static_cast<size_t>(k) * stride_bytes, sizeof(oalsfx_effect));
+        mark_touched(b, instances[k], 1);
+    }
+    return 1;
+}
+
 int oalsfx_batch_set_effect_type(oalsfx_batch* b, int first, int count, int slot, int effect_type)
 {
     if (!range_ok(b, first, count)) return 0;

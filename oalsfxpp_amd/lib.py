@@ -25,6 +25,7 @@ SIGNATURES = {
     "oalsfx_batch_sampling_rate": (C.c_int, [C.c_void_p]),
     "oalsfx_batch_effect_count": (C.c_int, [C.c_void_p]),
     "oalsfx_batch_set_effect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "oalsfx_batch_set_effect_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "oalsfx_batch_set_effect_type": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "oalsfx_batch_set_effect_props": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "oalsfx_batch_set_send_props": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(desc.SendProps)]),

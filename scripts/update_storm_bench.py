@@ -1,4 +1,7 @@
-"""Step time when a fraction of the instances gets a new preset before every buffer (4096 EAX reverbs, stereo, 256 frames)."""
+"""Step time when a fraction of the instances gets a new preset before every buffer (4096 EAX reverbs, stereo, 256 frames).
+  python3 scripts/update_storm_bench.py [k ...] [--per-call]
+The changed instances are set with one `set_effect_at` call per buffer; --per-call: one `set_effect` call per instance, as the script
+did until late in round 3 (forty foreign-function calls from Python cost 50 us)."""
 import random, sys, time
 sys.path.insert(0, ".")
 import torch
@@ -12,11 +15,18 @@ presets = []
 for i in range(113):
     e = lib.effect_defaults(desc.EAX_REVERB); e.props.reverb = lib.preset(i)[1]; presets.append(e)
 rng = random.Random(1)
-levels = [int(a) for a in sys.argv[1:]] or [0, 4, 40, 204, 1024]
+PER_CALL = "--per-call" in sys.argv
+levels = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [0, 4, 40, 204, 1024]
+def change(k):
+    picks = rng.sample(range(n), k)
+    if PER_CALL:
+        for i in picks:
+            b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
+    elif k:
+        b.set_effect_at(0, picks, [presets[rng.randrange(113)] for _ in picks])
 for k in levels:
     for _ in range(8):   # untimed: the same update rate, so that staging buffers have their size
-        for i in rng.sample(range(n), k):
-            b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
+        change(k)
         if k: b.apply_changes()
         b.mix_device(frames, src.data_ptr(), dst.data_ptr())
     b.synchronize()
@@ -25,8 +35,7 @@ for k in levels:
     t0 = time.perf_counter()
     for step in range(50):
         u0 = time.perf_counter()
-        for i in rng.sample(range(n), k):
-            b.set_effect(0, presets[rng.randrange(113)], first=i, count=1)
+        change(k)
         if k: b.apply_changes()
         u1 = time.perf_counter()
         t_upd += u1 - u0

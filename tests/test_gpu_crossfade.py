@@ -172,3 +172,34 @@ def test_a_storm_of_changes_among_many_instances():
         f.check_state()
     finally:
         f.close()
+
+
+def test_set_effect_at_is_set_effect_per_instance():
+    """`oalsfx_batch_set_effect_at` (instances that are not neighbours, one foreign call) against one `set_effect` call per instance:
+    same descriptors, same outputs; an index out of range sets nothing and reports."""
+    import pytest as _pytest
+    from oalsfxpp_amd.api import Batch, BatchError
+    n = 16
+    picks, to = [14, 3, 9], [20, 57, 101]
+    x = np.stack([np.sin(np.arange(256 * 2, dtype=np.float32) * (0.01 + 0.001 * i)).reshape(256, 2) for i in range(n)]).astype(np.float32)
+    outs = []
+    for at in (False, True):
+        with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+            b.set_effect(0, [preset_effect(i) for i in range(n)])
+            b.apply_changes()
+            for _ in range(3):
+                b.mix(x)
+            if at:
+                with _pytest.raises(BatchError):
+                    b.set_effect_at(0, [2, n], [preset_effect(1), preset_effect(2)])
+                b.set_effect_at(0, picks, [preset_effect(p) for p in to])
+            else:
+                for i, p in zip(picks, to):
+                    b.set_effect(0, preset_effect(p), first=i, count=1)
+            b.apply_changes()
+            ys = [b.mix(x).copy() for _ in range(3)]
+            params = [bytes(b.read_slot(i, 0)[0])[8:] for i in range(n)]   # (behind type and update_seq)
+            outs.append((ys, params))
+    for ya, yb in zip(outs[0][0], outs[1][0]):
+        assert (ya.view(np.uint32) == yb.view(np.uint32)).all()
+    assert outs[0][1] == outs[1][1]
