@@ -428,6 +428,23 @@ UncachedPool& uncached_pool()
     return *pool;
 }
 
+// Does this runtime hand out uncached device memory at all?  Asked once per device; where it does not, batches keep everything in
+// ordinary memory and their calls in stream order.
+bool uncached_memory_available(int device)
+{
+    static std::mutex m;
+    static std::map<int, bool> known;
+    std::lock_guard<std::mutex> lock(m);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    void* p = nullptr;
+    const bool ok = uncached_pool().take(device, 4096, &p) == hipSuccess;
+    if (ok) uncached_pool().give_back(p);
+    else (void)hipGetLastError();
+    known[device] = ok;
+    return ok;
+}
+
 hipError_t handed_on_malloc(const oalsfx_batch* b, void** p, size_t bytes)
 {
     const char* kind = std::getenv("OALSFX_RING_MEMORY");
@@ -1525,7 +1542,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
         // its records without waiting for its turn -- old lines in that CU's L1, found with 70 instances; every kind but the last is
         // whole workgroups anyway, steady_kind_counts)
         b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances & 3) == 0 && n_instances / 4 <= b->resident_groups &&
-                      (!kind || std::strcmp(kind, "uncached") == 0);
+                      (!kind || std::strcmp(kind, "uncached") == 0) && uncached_memory_available(b->device);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
     for (int k = 0; k < kSideStreams; ++k) {
