@@ -135,15 +135,17 @@ def test_a_run_of_chained_calls_ends_where_it_must():
             assert not s.compare_state()
 
 
-def test_many_chained_calls_at_full_size():
-    """4096 instances (every workgroup slot of the chip taken by each launch): 200 calls without a synchronisation in between, replicas
-    of one input against each other and a sample against the oracle at the end (state and delay lines carry every call's result)."""
+@pytest.mark.parametrize("n", [4096, 8192])
+def test_many_chained_calls_at_full_size(n):
+    """4096 instances (every workgroup slot of the chip taken by each launch), 8192 (two rounds of the chip per launch): 200 calls
+    without a synchronisation in between, replicas of one input against each other and a sample against the oracle at the end (state
+    and delay lines carry every call's result)."""
     import torch
-    n, frames, calls = 4096, 256, 200
+    frames, calls = 256, 200
     with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
         b.set_effect_type(0, desc.EAX_REVERB)
         b.apply_changes()
-        sample = [0, 1, 1023, 2048, 4095]
+        sample = [0, 1, 1023, 2048, 4095, n - 1]
         shadows = {i: OracleShadow(b, i) for i in sample}
         for s in shadows.values():
             s.sync()
