@@ -1633,8 +1633,18 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, i
         SteadyShared<CH, 4, false, true, true> believed; // XF
     };
     __shared__ Shared sh;
-    // in CU-major order: the workgroups that share a CU run the same build (as far as the kinds' sizes allow)
-    int group = (flags & kNoCuMajor) ? static_cast<int>(blockIdx.x) : cu_major_position(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+    // The workgroups of the last kind -- believed or in a transition: the slowest build, 65 us per 256 frames where the proven ones take
+    // 40 -- are the grid's first: a launch dispatches its workgroups in order, and the ones that take longest should not be the ones that
+    // start last (with consecutive launches overlapping, a workgroup starts when a slot of the launch before is given up).
+    const int slow_groups = kinds.groups(3);
+    if (static_cast<int>(blockIdx.x) < slow_groups) {
+        reverb_steady_group<CH, 4, false, true, true, true, false, false, true, NF>(ctx, slot, list + kinds.count[0] + kinds.count[1] + kinds.count[2], kinds.count[3], flags,
+                                                                                     static_cast<int>(blockIdx.x), sh.believed);
+        return;
+    }
+    // the others in CU-major order: the workgroups that share a CU run the same build (as far as the kinds' sizes allow)
+    const int rest = static_cast<int>(blockIdx.x) - slow_groups;
+    int group = (flags & kNoCuMajor) ? rest : cu_major_position(rest, static_cast<int>(gridDim.x) - slow_groups);
     if (group < kinds.groups(0)) {
         reverb_steady_group<CH, 4, false, false, false, false, false, true, false, false, SF>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
         return;
@@ -1647,13 +1657,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, i
     }
     group -= kinds.groups(1);
     list += kinds.count[1];
-    if (group < kinds.groups(2)) {
-        reverb_steady_group<CH, 4, false, true, true, true, false, true>(ctx, slot, list, kinds.count[2], flags, group, sh.general);
-        return;
-    }
-    group -= kinds.groups(2);
-    list += kinds.count[2];
-    reverb_steady_group<CH, 4, false, true, true, true, false, false, true, NF>(ctx, slot, list, kinds.count[3], flags, group, sh.believed);
+    reverb_steady_group<CH, 4, false, true, true, true, false, true>(ctx, slot, list, kinds.count[2], flags, group, sh.general);
 }
 
 // General path for one instance on one wavefront: any cross-fade state, modulation, gain ramps, taps closer than a tile,
