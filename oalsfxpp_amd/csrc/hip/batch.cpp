@@ -54,6 +54,7 @@ constexpr int kSideStreams = 3; // ring-light effects, proven-steady reverbs, be
 #define OALSFX_CHAIN_DEPTH 3
 #endif
 constexpr int kChainDepth = OALSFX_CHAIN_DEPTH;
+static_assert(kChainDepth >= 1 && kChainDepth <= 3, "a wavefront looks at the CUs of the two launches before it (reverb.hip, turn_cu / turn_cu2): at most three launches in flight");
 
 struct oalsfx_batch {
     int n = 0, slots = 0, channels = 0, rate = 0, device = 0;
@@ -1293,6 +1294,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     if (chained) {
         ctx.turn = b->d_turn;
         ctx.turn_cu = b->d_turn + static_cast<size_t>(b->n) * b->slots + 16;
+        ctx.turn_cu2 = ctx.turn_cu + static_cast<size_t>(b->n) * b->slots;
         ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
         if (++b->turn_counter == 0u) b->turn_counter = 1u;
         ctx.turn_set = b->turn_counter;
@@ -1563,8 +1565,8 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_hot, 0, total * oalsfx_hip::hot::SIZE * sizeof(unsigned), b->stream), "hipMemsetAsync(hot records)");
     ok = ok && b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_inst_epoch), n_instances * sizeof(unsigned)), "hipMalloc(epochs)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_inst_epoch, 0, n_instances * sizeof(unsigned), b->stream), "hipMemsetAsync(epochs)");
-    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_turn), (2 * total + 16) * sizeof(unsigned)), "hipMalloc(turns)");
-    ok = ok && b->hip_ok(hipMemsetAsync(b->d_turn, 0, (2 * total + 16) * sizeof(unsigned), b->stream), "hipMemsetAsync(turns)");
+    ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_turn), (3 * total + 16) * sizeof(unsigned)), "hipMalloc(turns)");
+    ok = ok && b->hip_ok(hipMemsetAsync(b->d_turn, 0, (3 * total + 16) * sizeof(unsigned), b->stream), "hipMemsetAsync(turns)");
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_exact, 0, total * sizeof(unsigned), b->stream), "hipMemsetAsync(exact)");
     ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_exact), total * sizeof(unsigned)), "hipHostMalloc(exact)");

@@ -422,6 +422,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     //    there; s_dcache_inv costs nothing measurable.
     //  - The wait ends: the launch before has its workgroups on the chip before this one gets its first (batch.cpp, k_chain_gate), and
     //    a count-out reports through the fault word rather than hang.
+    unsigned cu_before = 0; // the CU the launch before ran this instance on (0: this launch is a run's first)
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
         if (valid && lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
@@ -437,17 +438,25 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #if OALSFX_CHAIN_EXP & 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
-        // One reader of the instance's lines is left that this launch's start did not come after: the instance's own wavefront of the
-        // launch before, which kept reading them while this launch was already on the chip (that is the overlap) and wrote some of them
-        // afterwards (an all-pass ring comes round within a call or two).  Whether a CU's L1 keeps such a line as it was read is not
-        // something this code relies on: where the hand-over stays on one CU -- the launch before leaves the CU's name beside the word --
-        // this wavefront does pay for the agent-scope acquire.  It does not happen in practice (0 of 4.9 million hand-overs,
-        // scripts/chain_probe.py): a workgroup is on the chip, waiting, before the one it waits for leaves its CU.
+        // Readers of the instance's lines are left that this launch's start did not come after: the instance's own wavefronts of the
+        // launches still in flight when this one started -- the launch before, and with three launches in flight the one before that --
+        // which kept reading them while this launch was already on the chip (that is the overlap); the lines have been written since (by
+        // those wavefronts themselves: an all-pass ring comes round within a call or two; by the launch in between).  A CU that one of
+        // them ran on may hold such a line as it was read.  So each launch leaves the CU's name beside the word, and the name the launch
+        // before it left one further on: where this wavefront runs on one of the two, it does pay for the agent-scope acquire
+        // (buffer_inv sc1: this CU's L1 dropped).  Rare on a full chip (a workgroup is on the chip, waiting, before the one it waits for
+        // leaves its CU); with few workgroups, whose places shift from launch to launch as instances change kind, it is what the random
+        // runs of tests/test_gpu_chained.py found: 35 of 6000 wrong with the launch before alone looked at, three launches in flight.
         {
-            unsigned before_cu = 0;
-            if (valid && lane == 0) before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned before_cu = 0, before_that_cu = 0;
+            if (valid && lane == 0) {
+                before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                before_that_cu = __hip_atomic_load(ctx.turn_cu2 + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             before_cu = __builtin_amdgcn_readfirstlane(before_cu);
-            if (before_cu == this_cu()) {
+            before_that_cu = __builtin_amdgcn_readfirstlane(before_that_cu);
+            cu_before = before_cu;
+            if (before_cu == this_cu() || before_that_cu == this_cu()) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
             } else {
@@ -1600,7 +1609,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     if (ctx.turn != nullptr && ctx.turn_set != 0u) {
         // this launch is through with the instance (its stores acknowledged): the next one may take it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (valid && lane == 0) __hip_atomic_store(ctx.turn_cu + sidx, this_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (where: see the wait)
+        if (valid && lane == 0) { // (where: see the wait)
+            __hip_atomic_store(ctx.turn_cu2 + sidx, cu_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctx.turn_cu + sidx, this_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
         if (valid && lane == 0) __hip_atomic_store(ctx.turn + sidx, ctx.turn_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

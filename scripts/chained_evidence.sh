@@ -24,7 +24,7 @@ echo "chained:" > $O/send_filters.txt; timeout -k 10 200 python3 scripts/send_fi
 echo "stream order:" >> $O/send_filters.txt; OALSFX_DEBUG_FLAGS=0x400 timeout -k 10 200 python3 scripts/send_filter_bench.py 2>/dev/null | grep -v "^$" >> $O/send_filters.txt
 echo "chained:" > $O/kinds_presets.txt; timeout -k 10 200 python3 scripts/kinds_presets_bench.py 2>/dev/null | grep step >> $O/kinds_presets.txt
 echo "stream order:" >> $O/kinds_presets.txt; OALSFX_DEBUG_FLAGS=0x400 timeout -k 10 200 python3 scripts/kinds_presets_bench.py 2>/dev/null | grep step >> $O/kinds_presets.txt
-for d in 2 4; do
+for d in 2; do
   if [ -f ab/liboalsfx_hip_d$d.so ]; then
     echo "launches in flight: $d" >> $O/chain_depth.txt
     OALSFX_LIB=ab/liboalsfx_hip_d$d.so timeout -k 10 100 python3 scripts/chain_probe.py 2>/dev/null | tail -1 >> $O/chain_depth.txt

@@ -424,14 +424,14 @@ def test_random_runs(seed):
 
         def change(instances):
             def op():
-                for i in instances:
-                    was = now[i]
+                before_op = dict((i, now[i]) for i in instances)
+                for i in instances:   # (an instance may come up twice: the last setter before the apply counts)
                     now[i] = rng.randrange(113)
-                    e = preset_effect(now[i], desc.EAX_REVERB)
-                    b.set_effect(0, e, first=i, count=1)
+                    b.set_effect(0, preset_effect(now[i], desc.EAX_REVERB), first=i, count=1)
+                for i, was in before_op.items():
                     # (the same preset again is no change: the reference compares deferred and active properties, and so does the batch)
                     if i in shadows and now[i] != was:
-                        p = lib.derive_slot(fmt, 48000, lib.effect_normalized(e))
+                        p = lib.derive_slot(fmt, 48000, lib.effect_normalized(preset_effect(now[i], desc.EAX_REVERB)))
                         p.update_seq = shadows[i].seq[0] + 1
                         shadows[i].oracle.set_slot(0, p, restart=False)
                         shadows[i].seq[0] = p.update_seq
