@@ -185,6 +185,7 @@ struct oalsfx_batch {
     hipStream_t chain_stream[kChainDepth] = {};   // [0] is `stream`; a run's launches take them in turn
     hipEvent_t ev_chain[kChainDepth] = {};
     int chain_pos = 0;                            // the stream of the last chained launch
+    int chain_pos_last = -1, chain_pos_before = -1; // ... of the launch before this call's, and of the one before that (-1: none in this run)
     bool chain_used[kChainDepth] = {};            // streams the current run has launched on
     hipEvent_t ev_chain_start = nullptr;          // recorded in front of a run's first launch: the second (other stream) starts no earlier
     unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups of chained launches that have started (k_chain_gate)
@@ -1258,6 +1259,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         int populated = 0;
         for (int k = 0; k < 3; ++k) populated += b->kind_count[0][k] > 0;
         const int depth = (populated > 1 || b->slow_count[0] > 0 || upload.st) ? kChainDepth : std::min(2, kChainDepth);
+        b->chain_pos_before = b->chain_open ? b->chain_pos_last : -1;
+        b->chain_pos_last = b->chain_open ? b->chain_pos : -1;
         b->chain_pos = b->chain_open ? (b->chain_pos + 1) % depth : 0;
         stream = b->chain_stream[b->chain_pos];
         first_on_its_stream = b->chain_open && !b->chain_used[b->chain_pos];
@@ -1295,6 +1298,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         ctx.turn = b->d_turn;
         ctx.turn_cu = b->d_turn + static_cast<size_t>(b->n) * b->slots + 16;
         ctx.turn_cu2 = ctx.turn_cu + static_cast<size_t>(b->n) * b->slots;
+        // (this launch sits behind the launch two before it in its stream -- two streams taking turns -- or that launch may still run)
+        ctx.turn_two_back = (b->chain_pos_before >= 0 && b->chain_pos_before != b->chain_pos) ? 1u : 0u;
         ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
         if (++b->turn_counter == 0u) b->turn_counter = 1u;
         ctx.turn_set = b->turn_counter;
@@ -1535,10 +1540,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     {
         // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
         const char* kind = std::getenv("OALSFX_RING_MEMORY");
-        // (whole workgroups only: the idle wavefronts of an incomplete workgroup run beside the first instance of their kind's list and read
-        // its records without waiting for its turn -- old lines in that CU's L1, found with 70 instances; every kind but the last is
-        // whole workgroups anyway, steady_kind_counts)
-        b->uncached = effect_count == 1 && b->channels <= 2 && (n_instances & 3) == 0 &&
+        b->uncached = effect_count == 1 && b->channels <= 2 &&
                       (!kind || std::strcmp(kind, "uncached") == 0) && uncached_memory_available(b->device);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");

@@ -60,6 +60,8 @@ struct KernelCtx {
     unsigned* turn_started;             // every workgroup counts itself in here as it starts (k_chain_gate)
     unsigned* turn_cu;                  // [instance][slots]: the CU the last chained launch ran the instance on (reverb.hip, this_cu)
     unsigned* turn_cu2;                 // ... and the one before it
+    unsigned turn_two_back;             // != 0: the launch before the last may still have been at work when this launch started (it is not
+                                        // the launch this one sits behind in its stream)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
     int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
                               // will not be run on them; one that is not steady after all is counted in `fault`

@@ -398,7 +398,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     float* utf = lds + kSteadyGroups * 4 * kRow;
     unsigned* utu = reinterpret_cast<unsigned*>(utf);
 
-    const int inst = (FP && ctx.list_first >= 0) ? ctx.list_first + (valid ? w : 0) : __builtin_amdgcn_readfirstlane(list[valid ? w : 0]);
+    // (the idle wavefronts of an incomplete workgroup run beside the workgroup's own first instance: they take part in its barriers and
+    // chain phases and need some instance's records to read -- one that this workgroup waits for anyway, see the wait below)
+    const int wa = valid ? w : group * NW;
+    const int inst = (FP && ctx.list_first >= 0) ? ctx.list_first + wa : __builtin_amdgcn_readfirstlane(list[wa]);
     const size_t sidx = static_cast<size_t>(inst) * ctx.slots + slot;
     typedef const __attribute__((address_space(4))) oalsfx_slot_params ConstSlotParams;
     ConstSlotParams& SP = *(ConstSlotParams*)(uintptr_t)(ctx.params + sidx);
@@ -413,10 +416,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     //    the L2s do not cache (hipDeviceMallocUncached, batch.cpp): what a wavefront stored is in memory, for every XCD to see, once its
     //    stores are acknowledged (s_waitcnt vmcnt(0), then the word).  (Agent-scope fences over cached memory -- a write-back of the L2
     //    per wavefront -- were measured first: 245 us per step instead of 50.)
-    //  - No cache line holds bytes of two instances (SlotStateLines, common.hpp), and nobody but this wavefront reads the instance's
-    //    lines in this launch (chained launches are grids of whole workgroups: the idle wavefronts of an incomplete one would run beside
-    //    the first instance of their kind's list and read its records without waiting -- batch.cpp): this CU's vector L1, emptied when
-    //    the launch started, holds none of them before the wait is over, and needs no invalidate behind it (an agent-scope acquire there
+    //  - No cache line holds bytes of two instances (SlotStateLines, common.hpp), and nobody reads the instance's lines in this launch
+    //    before its turn has come (the idle wavefronts of an incomplete workgroup, which run beside the workgroup's first instance, wait
+    //    for that instance's turn as well -- when they ran beside the first instance of their kind's list without waiting, that CU's
+    //    L1 held old lines of it: found with 70 instances, tests/test_gpu_chained.py): this CU's vector L1, emptied when the launch
+    //    started, holds none of them before the wait is over, and needs no invalidate behind it (an agent-scope acquire there
     //    -- buffer_inv sc1 -- cost 9 to 12 us per step, more than the overlap gains; profiles/r03k_chained_launches).  The scalar cache
     //    is another matter: it is not written through by vector stores, so a line the launch before loaded through it may still be
     //    there; s_dcache_inv costs nothing measurable.
@@ -425,7 +429,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned cu_before = 0; // the CU the launch before ran this instance on (0: this launch is a run's first)
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
-        if (valid && lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
+        if (lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
             unsigned spins = 0;
             while (__hip_atomic_load(ctx.turn + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ctx.turn_wait) {
                 __builtin_amdgcn_s_sleep(2);
@@ -449,14 +453,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // runs of tests/test_gpu_chained.py found: 35 of 6000 wrong with the launch before alone looked at, three launches in flight.
         {
             unsigned before_cu = 0, before_that_cu = 0;
-            if (valid && lane == 0) {
+            if (lane == 0) {
                 before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 before_that_cu = __hip_atomic_load(ctx.turn_cu2 + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             before_cu = __builtin_amdgcn_readfirstlane(before_cu);
             before_that_cu = __builtin_amdgcn_readfirstlane(before_that_cu);
             cu_before = before_cu;
-            if (before_cu == this_cu() || before_that_cu == this_cu()) {
+            // (the launch before the last counts only where it may have been at work when this launch started: the host knows -- this
+            // launch sits behind it in its stream, or it does not)
+            if (before_cu == this_cu() || (ctx.turn_two_back != 0u && before_that_cu == this_cu())) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
             } else {
