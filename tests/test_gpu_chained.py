@@ -397,15 +397,19 @@ def test_property_changes_inside_a_run(fmt, n):
             assert not d, f"instance {i}: " + "; ".join(d[:12])
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_SEEDS", "6"))))
+FULL_SIZE_SEEDS = [-1 - k for k in range(int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_FULL_SIZE", "2")))]
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_SEEDS", "6")))) + FULL_SIZE_SEEDS)
 def test_random_runs(seed):
     """Random sequences of device-buffer calls and preset changes with no synchronisation in between: whole-tile calls of every size,
     ragged ones (which end a run), changes the cross-fading build follows and changes it does not (general kernel: stream order), several
-    changes of one instance in a row, changes of many instances at once.  Every output buffer, then state and delay lines."""
+    changes of one instance in a row, changes of many instances at once.  Every output buffer, then state and delay lines.  Negative
+    seeds: 4096 instances (every workgroup slot of the chip taken, three launches in flight), a dozen of them followed."""
     import random
     rng = random.Random(9000 + seed)
     fmt = rng.choice([desc.FMT_MONO, desc.FMT_STEREO])
-    n = rng.choice([6, 8, 24, 30, 70, 72, 127, 128])
+    n = rng.choice([6, 8, 24, 30, 70, 72, 127, 128]) if seed >= 0 else 4096
     with Batch(n, fmt, 48000, 1) as b:
         now = [rng.randrange(113) for _ in range(n)]
         b.set_effect(0, [preset_effect(a, desc.EAX_REVERB) for a in now])
@@ -441,7 +445,7 @@ def test_random_runs(seed):
         for _ in range(40):
             r = rng.random()
             if r < 0.62:
-                script.append(rng.choice([64, 128, 256, 256, 256, 512, 1024]))
+                script.append(rng.choice([64, 128, 256, 256, 256, 512, 1024] if n < 4096 else [64, 128, 256, 256, 256, 512]))
             elif r < 0.70:
                 script.append(rng.choice([1, 63, 100, 300]))
             elif r < 0.92:
@@ -452,7 +456,7 @@ def test_random_runs(seed):
                 script.append(change(rng.sample(range(n), min(n, rng.choice([8, 20])))))
         script += [256, 256]
         before = b.chained_calls
-        run_device_calls(b, script, shadows, 15000 + 100 * seed)
+        run_device_calls(b, script, shadows, 15000 + 100 * seed, replicas=False)
         assert b.chained_calls > before or __import__("os").environ.get("OALSFX_TEST_CHAINED_ANYWAY")
         for i, s in shadows.items():
             d = s.compare_state()
