@@ -384,12 +384,14 @@ public:
     hipError_t take(int device, size_t bytes, void** p)
     {
         {
+            // the smallest block that is waiting, large enough and not more than twice as large (a process that goes through many batch
+            // shapes then keeps a block per size class rather than per size)
             std::lock_guard<std::mutex> lock(mutex_);
-            auto it = free_.find({device, bytes});
-            if (it != free_.end()) {
+            auto it = free_.lower_bound({device, bytes});
+            if (it != free_.end() && it->first.first == device && it->first.second <= 2 * bytes) {
                 *p = it->second;
+                live_[*p] = it->first;
                 free_.erase(it);
-                live_[*p] = {device, bytes};
                 return hipSuccess;
             }
         }
