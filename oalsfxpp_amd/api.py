@@ -203,6 +203,12 @@ class Batch:
         """mix_device calls (own stream) that overlapped with their neighbours on the device so far."""
         return self._lib.oalsfx_batch_chained_calls(self._h)
 
+    def chain_started(self):
+        """(host count, device count) of the workgroups of chained launches started so far: the two must agree.  Waits."""
+        h, d = C.c_uint(0), C.c_uint(0)
+        self._check(self._lib.oalsfx_debug_chain_started(self._h, C.byref(h), C.byref(d)))
+        return h.value, d.value
+
     @property
     def last_reverb_kernel(self):
         return (self._lib.oalsfx_batch_last_reverb_kernel(self._h) or b"").decode()

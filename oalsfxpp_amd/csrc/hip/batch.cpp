@@ -27,6 +27,7 @@
 #include "../host/core.hpp"
 #include "common.hpp"
 #include "oalsfx_hip.h"
+#include "oalsfx_hip_debug.h"
 
 using namespace oalsfx_host;
 using oalsfx_hip::KernelCtx;
@@ -191,6 +192,8 @@ struct oalsfx_batch {
     unsigned* d_turn = nullptr;                   // [n*slots], then the count of workgroups of chained launches that have started (k_chain_gate)
     uint32_t turn_counter = 0;                    // the number the last chained launch set
     uint32_t started_total = 0;                   // what that count comes to once the last chained launch has started as a whole
+    int launched_groups = 0;                      // workgroups of the call's steady-state reverb launch (what its chained launch adds to that count)
+    bool poisoned = false;                        // a chained launch gave up waiting: some instance missed a buffer; every later call fails
     int chain_len = 0;                            // launches in the current run
     std::vector<std::pair<const char*, const char*>> chain_dsts; // ... and their output buffers
     bool uncached = false;                        // what launches hand on lives in uncached memory: calls can be chained launches
@@ -440,10 +443,17 @@ bool uncached_memory_available(int device)
     std::lock_guard<std::mutex> lock(m);
     auto it = known.find(device);
     if (it != known.end()) return it->second;
-    void* p = nullptr;
-    const bool ok = uncached_pool().take(device, 4096, &p) == hipSuccess;
-    if (ok) uncached_pool().give_back(p);
-    else (void)hipGetLastError();
+    // The hand-over between launches that run at the same time (reverb.hip) rests on how this part's caches behave -- an acknowledged
+    // store to uncached memory is in memory for every XCD, a launch starts with empty vector L1s, HW_REG_XCC_ID names the XCD -- and has
+    // been validated on gfx950 only: any other device keeps its calls in stream order (ADVICE, round 3).
+    hipDeviceProp_t prop{};
+    bool ok = hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    if (ok) {
+        void* p = nullptr;
+        ok = uncached_pool().take(device, 4096, &p) == hipSuccess;
+        if (ok) uncached_pool().give_back(p);
+        else (void)hipGetLastError();
+    }
     known[device] = ok;
     return ok;
 }
@@ -966,9 +976,11 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
     c.no_follow_up = lead;
     {
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
+        int groups = 0;
         const char* name = oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0,
-                                                            b->modulated[slot], b->n_short[slot] > 0, proven, !proven && slot_in_transition(b, slot), stream);
+                                                            b->modulated[slot], b->n_short[slot] > 0, proven, !proven && slot_in_transition(b, slot), stream, &groups);
         if (name) b->last_steady_kernel = name;
+        b->launched_groups += groups;
     }
     if (hand_over && count > lead) {
         ScopedTiming timing(b, OALSFX_REVERB + kTimedGeneralOffset, stream);
@@ -1027,10 +1039,12 @@ void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, i
     const bool one_kind = counts[3] == 0 && (counts[0] > 0) + (counts[1] > 0) + (counts[2] > 0) == 1;
     c.list_first = one_kind ? b->fast_first[slot] : -1;
     ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
+    int groups = 0;
     const char* name = oalsfx_hip::launch_reverb_steady_kinds(c, slot, b->d_lists + b->steady_offset[slot], counts,
                                                               flags | ((debug_flags() & 0xFF) << 8) | ((debug_flags() & 0x100) ? oalsfx_hip::kNoCuMajor : 0),
-                                                              (debug_flags() & 0x1000000) != 0, filters_inside, stream);
+                                                              (debug_flags() & 0x1000000) != 0, filters_inside, stream, &groups);
     if (name) b->last_steady_kernel = name;
+    b->launched_groups += groups;
 }
 
 // The general kernel takes the instances of both reverb types that are not believed steady, or every reverb instance of
@@ -1152,6 +1166,9 @@ bool check_fault(oalsfx_batch* b)
     if (f >= oalsfx_hip::kFaultTurn) {
         std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady).",
                       f, (f / oalsfx_hip::kFaultTurn) & 0xFFFu, f / oalsfx_hip::kFaultGate, f & 0xFFFu);
+        // (the instances concerned were left alone, and so were the launches behind them in the run: the batch's state is a buffer short
+        // there.  No further call pretends otherwise.)
+        b->poisoned = true;
         return b->fail(b->fault_text);
     }
     return b->fail("Internal error: a reverb instance listed as proven steady was not; its buffer was left unprocessed.");
@@ -1243,6 +1260,7 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
 
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream, bool may_chain = false)
 {
+    if (b->poisoned) return b->fail(b->fault_text);
     poll_exact(b);
     // what has changed since the last call: the host's part first (it decides what this call launches), the upload itself below, where
     // the call's launches go
@@ -1337,7 +1355,6 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             }
         }
         ctx.turn_started = started;
-        b->started_total += static_cast<uint32_t>((b->n + 3) / 4);
         // Parameters that changed since the call before: put in place on this launch's stream, behind the gate -- beside the launch
         // before, which may still be at work with the old ones: a slot's record (and its instance's epoch) is stored once that launch is
         // through with the instance; a rebuilt list went to the buffer that launch does not read.
@@ -1348,6 +1365,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
+    b->launched_groups = 0;
     // Api::mix chunking (reference src/oalsfxpp.cpp:3818-3826)
     for (int done = 0; done < frames;) {
         const int n = std::min(frames - done, OALSFX_MAX_CHUNK);
@@ -1453,6 +1471,13 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 if (!b->hip_ok(hipStreamWaitEvent(stream, b->ev_join[k], 0), "hipStreamWaitEvent")) return false;
         }
         done += n;
+    }
+    if (chained) {
+        // every workgroup of the launch counts itself in on the device (reverb.hip, turn_started): the grid as launched, which for a grid
+        // of several kinds is up to three workgroups more than a quarter of the instances (ADVICE, round 3: the host added (n + 3) / 4
+        // and drifted behind the device's count by up to three per call)
+        if (b->launched_groups <= 0) return b->fail("Internal error: a chained call launched no steady-state grid.");
+        b->started_total += static_cast<uint32_t>(b->launched_groups);
     }
     if ((frames % OALSFX_MAX_CHUNK) & 63) {
         // a ragged chunk: a cross-fade in flight no longer stands at a tile boundary, which the XF build needs
@@ -2065,6 +2090,16 @@ long long oalsfx_debug_chain_same_cu(oalsfx_batch* b)
     if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || hipStreamSynchronize(b->stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, b->d_turn + static_cast<size_t>(b->n) * b->slots + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
+}
+
+int oalsfx_debug_chain_started(oalsfx_batch* b, unsigned* host_total, unsigned* device_total)
+{
+    unsigned v = 0;
+    if (!b->hip_ok(hipSetDevice(b->device), "hipSetDevice") || !chain_join(b) || !b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
+    if (b->d_turn && !b->hip_ok(hipMemcpy(&v, b->d_turn + static_cast<size_t>(b->n) * b->slots, sizeof(v), hipMemcpyDeviceToHost), "hipMemcpy")) return 0;
+    if (host_total) *host_total = b->started_total;
+    if (device_total) *device_total = v;
+    return 1;
 }
 
 int oalsfx_device_pci_bus_id(int device_id, char* out, int len)

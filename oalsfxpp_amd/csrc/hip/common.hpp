@@ -130,8 +130,10 @@ constexpr unsigned kPlainMinTap = 192;
 // in_transition: some listed instance had its properties changed less than a cross-fade ago, in a way the XF build can follow (mono /
 // stereo, whole tiles, not proven): that build.
 // Returns the kernel symbol it launched (template arguments as rocprofv3 prints them), nullptr when the list was empty.
+// groups (may be nullptr): receives the number of workgroups launched -- each counts itself in at ctx.turn_started, and the host's gate
+// in front of the next chained launch is set by that number (batch.cpp, started_total).
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated,
-                                 bool short_taps, bool proven, bool in_transition, hipStream_t stream);
+                                 bool short_taps, bool proven, bool in_transition, hipStream_t stream, int* groups = nullptr);
 // The steady reverbs of a slot listed by kind (mono / stereo, whole tiles): counts[0] proven, every tap two tiles away; [1] proven, a tap
 // of one to two tiles; [2] proven, shorter taps or a modulated late line; [3] believed steady or in a transition the XF build follows.
 // One kind alone runs its own lean kernel, several share one grid whose workgroups take the build of their kind.
@@ -139,7 +141,7 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // filters_inside: some instance of the first two kinds has a send filter switched on and the batch has one slot: those kinds run the SF
 // builds (send filters inside, flag kFilterInside), and the pre-pass need not know them.
 const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
-                                       hipStream_t stream);
+                                       hipStream_t stream, int* groups = nullptr);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments

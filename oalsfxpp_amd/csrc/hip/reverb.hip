@@ -386,7 +386,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w = group * NW + wib;
-    const bool valid = w < count;
+    bool valid = w < count; // (cleared when the instance's turn in a run of chained launches never came: the wavefront then only keeps its workgroup company)
     const int lane = threadIdx.x & 63;
     const int frames = ctx.frames;
     const bool first = (flags & kFirst) != 0;
@@ -425,20 +425,26 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     //    is another matter: it is not written through by vector stores, so a line the launch before loaded through it may still be
     //    there; s_dcache_inv costs nothing measurable.
     //  - The wait ends: the launch before has its workgroups on the chip before this one gets its first (batch.cpp, k_chain_gate), and
-    //    a count-out reports through the fault word rather than hang.
+    //    a count-out reports through the fault word rather than hang.  An instance whose turn did not come is left alone -- nothing of
+    //    it is read into the tile loop, nothing written, its word stays as it is, so that the launches behind count out on it too
+    //    instead of working on what this one skipped -- and the host, which sees the fault word at its next synchronising call, fails
+    //    that call and every later one of the batch (check_fault, batch.cpp).
     unsigned cu_before = 0; // the CU the launch before ran this instance on (0: this launch is a run's first)
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
+        int lost = 0;
         if (lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
             unsigned spins = 0;
             while (__hip_atomic_load(ctx.turn + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ctx.turn_wait) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 20)) {
-                    if (ctx.fault) __hip_atomic_fetch_add(ctx.fault, kFaultTurn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (ctx.fault && valid) __hip_atomic_fetch_add(ctx.fault, kFaultTurn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    lost = 1;
                     break;
                 }
             }
         }
+        if (__builtin_amdgcn_readfirstlane(lost)) valid = false;
 #if OALSFX_CHAIN_EXP & 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #else
@@ -888,7 +894,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     auto store4 = [&](unsigned p4, auto ring, float v0, float v1, float v2, float v3) {
         constexpr int r = decltype(ring)::value;
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * r);
+#ifdef OALSFX_ABLATE_STORE_ALIGN // timing experiment (scripts/ablate_store_align.sh): ring stores rounded down to whole lines, results wrong
+        const unsigned wp = ((((p4 - 4u * static_cast<unsigned>(lane)) & ~static_cast<unsigned>(OALSFX_ABLATE_STORE_ALIGN - 1)) + 4u * static_cast<unsigned>(lane))) & utu[ut::BMASK + r];
+#else
         const unsigned wp = p4 & utu[ut::BMASK + r];
+#endif
         st_ring<r>(slab_b, wp | lo.x, v0); st_ring<r>(slab_b, wp | lo.y, v1); st_ring<r>(slab_b, wp | lo.z, v2); st_ring<r>(slab_b, wp | lo.w, v3);
     };
     // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 4 * NW
@@ -2358,8 +2368,9 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
         return "k_reverb_steady_coop<" #__VA_ARGS__ ">";                                                                         \
     } while (0)
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
-                                 bool proven, bool in_transition, hipStream_t stream)
+                                 bool proven, bool in_transition, hipStream_t stream, int* groups)
 {
+    if (groups) *groups = count > 0 ? (count + 3) / 4 : 0;
     if (count <= 0) return nullptr;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
@@ -2414,9 +2425,10 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // tap of one to two tiles, [2] proven with shorter taps or a modulated late line, [3] believed steady or in a transition the XF build
 // follows; `list` holds them in this order.  One kind alone takes its lean kernel, several share the grid of k_reverb_steady_kinds.
 const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
-                                       hipStream_t stream)
+                                       hipStream_t stream, int* groups_out)
 {
     const int total = counts[0] + counts[1] + counts[2] + counts[3];
+    if (groups_out) *groups_out = total > 0 ? (total + 3) / 4 : 0; // (one kind alone: its lean kernel; the grid of kinds says below what it takes)
     if (total <= 0) return nullptr;
     int populated = 0, only = 0;
     for (int k = 0; k < 4; ++k)
@@ -2434,13 +2446,14 @@ const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int
             return "k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true>";
         }
         // (close_taps / modulated / short_taps select the FP build of the kind; the believed kind alone: the XF build with the general path inside)
-        return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream);
+        return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream, groups_out);
     }
     KernelCtx c = ctx;
     c.list_first = -1; // (the kinds read their entries from the list)
     SteadyKinds kinds{};
     int groups = 0;
     for (int k = 0; k < 4; ++k) { kinds.count[k] = counts[k]; groups += kinds.groups(k); }
+    if (groups_out) *groups_out = groups;
     const dim3 grid(groups), block(256);
 #define OALSFX_KINDS(...)                                                                                  \
     do {                                                                                                   \

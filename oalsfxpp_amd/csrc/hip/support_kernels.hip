@@ -349,17 +349,23 @@ __global__ __launch_bounds__(256) void k_upload(UploadJobs jobs)
                 const size_t to = static_cast<size_t>(sj.indices[k]) * n; // (read beside the record, not in front of it)
                 if (base == 0 && sj.takes_turns && jobs.turn != nullptr && jobs.turn_wait != 0u) {
                     // chained launches: the launch before this upload's may still be at work on the instance, with the record as it is
+                    // (a wait that counts out leaves the record alone: that launch is still reading it; the fault word fails the batch's
+                    // next synchronising call and every call after it)
+                    __shared__ int lost;
                     if (t == 0) {
                         unsigned spins = 0;
+                        lost = 0;
                         while (__hip_atomic_load(jobs.turn + sj.indices[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != jobs.turn_wait) {
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > (1u << 20)) {
                                 if (jobs.fault) __hip_atomic_fetch_add(jobs.fault, kFaultTurn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                lost = 1;
                                 break;
                             }
                         }
                     }
                     __syncthreads();
+                    if (lost) return;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)

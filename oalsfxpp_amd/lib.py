@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liboalsfx_hip.so")
 _fp = C.POINTER(C.c_float)
 _lib = None
 
-# name -> (restype, argtypes); every symbol include/oalsfx_hip.h declares
+# name -> (restype, argtypes); every symbol include/oalsfx_hip.h and include/oalsfx_hip_debug.h declare
 SIGNATURES = {
     "oalsfx_batch_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "oalsfx_batch_destroy": (None, [C.c_void_p]),
@@ -54,6 +54,7 @@ SIGNATURES = {
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_batch_chained_calls": (C.c_longlong, [C.c_void_p]),
     "oalsfx_debug_chain_same_cu": (C.c_longlong, [C.c_void_p]),
+    "oalsfx_debug_chain_started": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "oalsfx_debug_set_flags": (None, [C.c_int]),
     "oalsfx_debug_ring_address": (C.c_ulonglong, [C.c_void_p, C.c_int, C.c_int]),

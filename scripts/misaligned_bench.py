@@ -1,12 +1,13 @@
 """256-frame calls of the headline loop after one odd-sized call: the delay lines' write position is then no longer on a cache-line
-boundary (a line holds 8 frames of a 4-line ring) and stays off it for good.  python3 scripts/misaligned_bench.py"""
+boundary (a line holds 8 frames of a 4-line ring) and stays off it for good.  python3 scripts/misaligned_bench.py [first call sizes]"""
 import sys, time
 sys.path.insert(0, ".")
 import torch
 from oalsfxpp_amd import desc
 from oalsfxpp_amd.api import Batch
 n, frames = 4096, 256
-for first in (0, 441, 100, 37):
+firsts = [int(a) for a in sys.argv[1:]] or [0, 441, 100, 37]
+for first in firsts:
     b = Batch(n, desc.FMT_STEREO, 48000, 1)
     b.set_effect_type(0, desc.EAX_REVERB); b.apply_changes()
     src = torch.empty(n * 512 * 2, device="cuda").uniform_(-1, 1); dst = torch.empty_like(src)

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads without a GPU, exports every symbol include/oalsfx_hip.h declares, agrees with
+"""CPU: the C-ABI library loads without a GPU, exports every symbol include/oalsfx_hip.h and include/oalsfx_hip_debug.h declare, agrees with
 the ctypes mirror on struct sizes, and refuses loudly to create a batch when no HIP device is usable."""
 import ctypes as C
 import os
@@ -13,11 +13,11 @@ from oalsfxpp_amd import desc, lib
 from oalsfxpp_amd.api import Batch, BatchError
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "oalsfx_hip.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("oalsfx_hip.h", "oalsfx_hip_debug.h")]
 
 
 def declared_functions():
-    text = open(HEADER).read()
+    text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned)_\w+)\s*\(", text)))
 
@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert len(names) >= 30
     so = C.CDLL(lib.LIB_PATH)
     for n in names:
-        assert hasattr(so, n), f"{n} is declared in oalsfx_hip.h but not exported"
+        assert hasattr(so, n), f"{n} is declared in include/ but not exported"
         assert n in lib.SIGNATURES, f"{n} has no ctypes prototype in oalsfxpp_amd/lib.py"
     assert set(lib.SIGNATURES) == set(names)
 
@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_sizes_match_the_c_headers():
     src = r'''
     #include <stdio.h>
-    #include "oalsfx_hip.h"
+    #include "oalsfx_hip_debug.h"
     int main(void) {
         printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(oalsfx_slot_params), sizeof(oalsfx_slot_state), sizeof(oalsfx_source_params),
                sizeof(oalsfx_source_state), sizeof(oalsfx_effect), sizeof(oalsfx_send_props), sizeof(oalsfx_reverb_params));

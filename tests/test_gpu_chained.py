@@ -461,3 +461,66 @@ def test_random_runs(seed):
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"seed {seed}, instance {i}: " + "; ".join(d[:4])
+
+
+def test_the_gate_counts_of_host_and_device_agree_over_a_long_run_of_several_kinds():
+    """The gate in front of a chained launch waits until all but a few workgroups of the launch before have started: the host's running
+    total against the count every workgroup adds itself to on the device.  A grid of several kinds holds up to three workgroups more
+    than a quarter of its instances (every kind starts a new workgroup), and round 3's host added (n + 3) / 4 per launch: the two
+    drifted apart by up to three per call, so that after some thousands of calls the gate no longer held a launch back at all
+    (ADVICE, round 3).  The host now adds the grid as launched.  21 instances of three kinds of presets (5 + 7 + 9: nine workgroups where
+    a quarter of the instances is six), one of them changing preset now and then (the believed kind's workgroup comes and goes),
+    2400 calls without a synchronisation; four instances against the oracle, every buffer."""
+    from harness import crossfade_followable, reverb_params
+    import random
+    rng = random.Random(77)
+    params = [reverb_params(preset_effect(i)) for i in range(113)]
+    # presets by the kind of build their taps need at 48 kHz (kPlainMinTap, hip/common.hpp)
+    kinds = {}
+    for p in range(113):
+        t = params[p]
+        taps = list(t.early_tap) + list(t.early_ap_off) + list(t.early_line_off) + [x - t.late_feed_tap for x in t.late_tap] + list(t.late_ap_off) + list(t.late_line_off)
+        kinds.setdefault("plain" if min(taps) >= 192 and t.mod_depth == 0.0 else "close" if min(taps) >= 64 and t.mod_depth == 0.0 else "short", []).append(p)
+    assert all(len(v) >= 2 for v in kinds.values()), {k: len(v) for k, v in kinds.items()}
+    start = [kinds["plain"][i % len(kinds["plain"])] for i in range(5)] + [kinds["close"][i % len(kinds["close"])] for i in range(7)] + \
+            [kinds["short"][i % len(kinds["short"])] for i in range(9)]
+    n = len(start)
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect(a) for a in start])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 4, 11, 20)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        now = list(start)
+
+        def change(i):
+            def op():
+                choices = [c for c in range(113) if c != now[i] and crossfade_followable(params[now[i]], params[c])]
+                now[i] = rng.choice(choices)
+                e = preset_effect(now[i])
+                b.set_effect(0, e, first=i, count=1)
+                b.apply_changes()
+            op.feeds_the_oracle_itself = True   # (instance 2 is not followed)
+            return op
+
+        script = []
+        for k in range(2400):
+            if k % 157 == 100:
+                script.append(change(2))
+            script.append(64)
+        before = b.chained_calls
+        h0, d0 = b.chain_started()
+        assert h0 == d0, (h0, d0)
+        run_device_calls(b, script, shadows, 21000)
+        assert b.chained_calls - before >= 2390, b.chained_calls - before
+        h1, d1 = b.chain_started()
+        assert h1 == d1, f"host {h1} and device {d1} disagree after {b.chained_calls - before} chained calls"
+        assert (h1 - h0) % (1 << 32) > (b.chained_calls - before) * ((n + 3) // 4), "the grids of this run were meant to hold more workgroups than a quarter of the instances"
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
