@@ -193,6 +193,14 @@ struct oalsfx_batch {
     uint32_t turn_counter = 0;                    // the number the last chained launch set
     uint32_t started_total = 0;                   // what that count comes to once the last chained launch has started as a whole
     int launched_groups = 0;                      // workgroups of the call's steady-state reverb launch (what its chained launch adds to that count)
+    // Where the delay lines' write positions stand on the 128-byte line grid (32 frames of a ring line): a slot's position is the frames
+    // mixed since its state was last started.  After a call that was not a multiple of 32 frames every ring store of a tile begins and
+    // ends inside a line; the plain FP build then takes its line-aligned variant (reverb.hip, CR == 2).  A speed hint: the kernel goes by
+    // the position it finds in the state.
+    uint32_t frames_total = 0;                    // frames mixed by the batch so far (wraps)
+    std::vector<uint32_t> started_at;             // [n*slots] frames_total when the slot's state was last started
+    bool off_grid_known = false;                  // off_grid[] is up to date
+    int off_grid[OALSFX_MAX_SLOTS] = {};          // per slot: reverbs whose write position is not a multiple of 32 frames
     bool poisoned = false;                        // a chained launch gave up waiting: some instance missed a buffer; every later call fails
     int chain_len = 0;                            // launches in the current run
     std::vector<std::pair<const char*, const char*>> chain_dsts; // ... and their output buffers
@@ -279,7 +287,7 @@ constexpr int kSettleFrames = OALSFX_RV_FADE_SAMPLES; // the cross-fade (128 fra
 enum : uint8_t {
     kClassReverb = 1,  // reverb or EAX reverb
     kClassSteady = 2,  // parameters the steady-state kernel builds accept
-    kClassClose = 4,   // shortest tap distance 64 .. kPlainMinTap - 1 samples (the HY builds)
+    kClassClose = 4,   // shortest tap distance 64 .. kPlainMinTap - 1 samples, or an early tap / late-line offset under kPlainMinTapAhead (the HY builds)
     kClassShort = 8,   // shortest tap distance below 64 samples
     kClassModulated = 16,
 };
@@ -290,7 +298,7 @@ uint8_t classify_slot(const oalsfx_slot_params& sp)
     const oalsfx_reverb_params& p = sp.u.reverb;
     uint8_t cls = kClassReverb | kClassSteady;
     const int sway = p.mod_depth != 0.0F ? 1 + static_cast<int>(std::abs(p.mod_depth)) : 0; // a modulated late line reads that much closer
-    int lo = 1 << 30;
+    int lo = 1 << 30, lo_ahead = 1 << 30; // (lo_ahead: early taps and late-line offsets, kPlainMinTapAhead)
     for (int j = 0; j < 4; ++j) {
         // what the most general build of the steady-state kernel accepts: early / late taps and early-line offsets of any length,
         // all-pass offsets from four samples, late-line offsets from one tile
@@ -298,8 +306,9 @@ uint8_t classify_slot(const oalsfx_slot_params& sp)
             p.late_line_off[j] < 64 + sway || p.late_tap[j] < p.late_feed_tap)
             cls &= static_cast<uint8_t>(~kClassSteady);
         lo = std::min({lo, p.early_tap[j], p.early_ap_off[j], p.early_line_off[j], p.late_tap[j] - p.late_feed_tap, p.late_ap_off[j], p.late_line_off[j]});
+        lo_ahead = std::min({lo_ahead, p.early_tap[j], p.late_line_off[j]});
     }
-    if (lo >= 64 && lo < static_cast<int>(oalsfx_hip::kPlainMinTap)) cls |= kClassClose;
+    if (lo >= 64 && (lo < static_cast<int>(oalsfx_hip::kPlainMinTap) || lo_ahead < static_cast<int>(oalsfx_hip::kPlainMinTapAhead))) cls |= kClassClose;
     if (lo < 64) cls |= kClassShort;
     if (p.mod_depth != 0.0F) cls |= kClassModulated;
     return cls;
@@ -657,6 +666,8 @@ bool prepare_params(oalsfx_batch* b, PendingUpload& pu)
                 b->h_state_init[idx].seen_seq = p.update_seq - 1;
                 up_state.push_back(static_cast<int>(idx));
                 restarted.push_back(idx);
+                b->started_at[idx] = b->frames_total;
+                b->off_grid_known = false;
                 release_slab(b, idx);
                 const size_t floats = static_cast<size_t>(ring_floats_for(p.type, b->rate));
                 if (floats) need[floats] += 1;
@@ -911,7 +922,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
 // general path inside (experiment: what the fallback's scratch frame costs the grid), 0x200 no send filters inside the steady-state
 // builds (the pre-pass kernel for every filtered instance, as before round 3), 0x400 no chained launches: consecutive calls in plain
-// stream order (bench.py --no-chain), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
+// stream order (bench.py --no-chain), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
+// before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
 // of tests/test_gpu_chained.py: it must fail).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
 // delay lines, state and hot records live), OALSFX_HOST_PROFILE (what the host spends in prepare_params, printed by synchronize)
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
@@ -954,6 +966,20 @@ constexpr int kTimedMixed = -2;       // ... of the grid that serves ring-light 
 // Can the steady-state kernel be used for this chunk at all?
 bool steady_kernel_usable(const KernelCtx& ctx) { return ctx.frames >= 1 && !(debug_flags() & 8); } // any call size: a short call is one partial tile
 
+// Does some reverb of the slot write its delay lines off the 128-byte line grid?  (Recounted after a call that was not a multiple of 32
+// frames and after a slot restarted: every position moves with every call, by the same amount.)
+bool slot_off_grid(oalsfx_batch* b, int slot)
+{
+    if (!b->off_grid_known) {
+        for (int s = 0; s < b->slots; ++s) b->off_grid[s] = 0;
+        const size_t total = static_cast<size_t>(b->n) * b->slots;
+        for (size_t idx = 0; idx < total; ++idx)
+            if ((b->slot_class[idx] & kClassReverb) && ((b->frames_total - b->started_at[idx]) & 31u) != 0u) b->off_grid[idx % b->slots] += 1;
+        b->off_grid_known = true;
+    }
+    return b->off_grid[slot] > 0 && !(debug_flags() & 0x4000);
+}
+
 // One steady-state launch for steady instances of both reverb types (adjacent in the list; the kernel reads the type per
 // instance): the proven ones (`proven`: the builds without steady-state test and general path), the believed ones, or both
 // together through the believing builds.
@@ -978,7 +1004,8 @@ void launch_reverb_steady_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, 
         ScopedTiming timing(b, OALSFX_EAX_REVERB, stream);
         int groups = 0;
         const char* name = oalsfx_hip::launch_reverb_steady(c, slot, list, count, flags | ((debug_flags() & 0xFF) << 8), b->n_close[slot] > 0,
-                                                            b->modulated[slot], b->n_short[slot] > 0, proven, !proven && slot_in_transition(b, slot), stream, &groups);
+                                                            b->modulated[slot], b->n_short[slot] > 0, proven, !proven && slot_in_transition(b, slot), stream, &groups,
+                                                            proven && slot_off_grid(b, slot));
         if (name) b->last_steady_kernel = name;
         b->launched_groups += groups;
     }
@@ -1042,7 +1069,7 @@ void launch_reverb_kinds_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, i
     int groups = 0;
     const char* name = oalsfx_hip::launch_reverb_steady_kinds(c, slot, b->d_lists + b->steady_offset[slot], counts,
                                                               flags | ((debug_flags() & 0xFF) << 8) | ((debug_flags() & 0x100) ? oalsfx_hip::kNoCuMajor : 0),
-                                                              (debug_flags() & 0x1000000) != 0, filters_inside, stream, &groups);
+                                                              (debug_flags() & 0x1000000) != 0, filters_inside, stream, &groups, slot_off_grid(b, slot));
     if (name) b->last_steady_kernel = name;
     b->launched_groups += groups;
 }
@@ -1485,6 +1512,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             if (b->xf_ok[idx]) { b->xf_ok[idx] = 0; b->lists_dirty = true; }
     }
     advance_settling(b, frames);
+    b->frames_total += static_cast<uint32_t>(frames);
+    if (frames & 31) b->off_grid_known = false;
     if (b->exact_wanted && !b->exact_pending) {
         // what this call's kernels found out about the reverbs that are not proven steady yet, fetched behind them
         const size_t total = static_cast<size_t>(b->n) * b->slots;
@@ -1537,6 +1566,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     b->inst.resize(n_instances);
     b->h_params.assign(total, oalsfx_slot_params{});
     b->h_state_init.assign(total, oalsfx_slot_state{});
+    b->started_at.assign(total, 0);
     b->h_source.assign(n_instances, oalsfx_source_params{});
     b->seq.assign(total, 0);
     b->h_rings.assign(total, nullptr);

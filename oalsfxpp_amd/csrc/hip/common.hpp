@@ -119,6 +119,9 @@ constexpr int kWave = 64;
 // written (late taps: from the late feed): three tiles, so that the aligned windows it requests a tile ahead (reverb.hip, OALSFX_AW)
 // never reach samples that are still being written.  The host sorts proven instances into kinds by the same number (batch.cpp).
 constexpr unsigned kPlainMinTap = 192;
+// ... and its early taps and late-line offsets 32 samples more: those two groups' windows are requested before the tile's stores to
+// their rings are issued, and the line-aligned stores (reverb.hip, CR) hold a tile's last samples back by up to 31
+constexpr unsigned kPlainMinTapAhead = 224;
 
 // ---- launchers (defined next to their kernels) ----
 // The host splits every reverb list into the instances it believes steady and the rest (a speed hint: the steady-state
@@ -130,10 +133,12 @@ constexpr unsigned kPlainMinTap = 192;
 // in_transition: some listed instance had its properties changed less than a cross-fade ago, in a way the XF build can follow (mono /
 // stereo, whole tiles, not proven): that build.
 // Returns the kernel symbol it launched (template arguments as rocprofv3 prints them), nullptr when the list was empty.
+// carry: the write position of some listed instance is off the 128-byte line grid of its delay lines (an odd-sized call came before):
+// the plain FP build that writes every ring line in whole cache lines (reverb.hip, CR == 2).
 // groups (may be nullptr): receives the number of workgroups launched -- each counts itself in at ctx.turn_started, and the host's gate
 // in front of the next chained launch is set by that number (batch.cpp, started_total).
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated,
-                                 bool short_taps, bool proven, bool in_transition, hipStream_t stream, int* groups = nullptr);
+                                 bool short_taps, bool proven, bool in_transition, hipStream_t stream, int* groups = nullptr, bool carry = false);
 // The steady reverbs of a slot listed by kind (mono / stereo, whole tiles): counts[0] proven, every tap two tiles away; [1] proven, a tap
 // of one to two tiles; [2] proven, shorter taps or a modulated late line; [3] believed steady or in a transition the XF build follows.
 // One kind alone runs its own lean kernel, several share one grid whose workgroups take the build of their kind.
@@ -141,7 +146,7 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // filters_inside: some instance of the first two kinds has a send filter switched on and the batch has one slot: those kinds run the SF
 // builds (send filters inside, flag kFilterInside), and the pre-pass need not know them.
 const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
-                                       hipStream_t stream, int* groups = nullptr);
+                                       hipStream_t stream, int* groups = nullptr, bool carry = false);
 void launch_reverb_general(const KernelCtx& ctx, int slot, const int* list, int count, int flags, hipStream_t stream);
 // every ring-light effect type of `slot_count` consecutive slots in one grid, one wavefront per listed instance (wave_effects.hip)
 // `seg` (single slots only, may be nullptr): the grid follows the list segment by segment, see WaveSegments

@@ -48,6 +48,7 @@ enum {
     LO = 24,     // 5 rings x 4 lines: byte offset of each line in the slab
     BMASK = 44,  // 5 rings: (len - 1) * 4
     FEED4 = 49,  // late_feed_tap * 4
+    CR_R = 50, CR_RF = 51, // line-aligned stores (CR builds): samples the call's write position / its late feed position lie past a 128-byte line
     ECOEF = 52, ELCOEF = 56,
     MISC = 60,   // density_gain, ap_feed_coeff, mix_x, mix_y
     LPB = 64, HPB = 68,        // b0, b1, b2 of the input shelves
@@ -142,6 +143,9 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 #endif
 #ifndef OALSFX_AW
 #define OALSFX_AW 1
+#endif
+#ifndef OALSFX_CR_FEED
+#define OALSFX_CR_FEED 0 // 1: the plain FP builds for write positions on the grid hold the late feed's stores back too (CR == 1; measured: no gain)
 #endif
 static_assert(!OALSFX_AW || kPlainMinTap >= 192, "aligned windows: a window requested a tile ahead may reach 63 samples past its tile's taps");
 template <int R> struct RingId { static constexpr int value = R; };
@@ -319,7 +323,7 @@ __device__ __forceinline__ void lds_barrier()
 // first shelf's feed-forward sums / output, the second shelf's -- and 64 floats of coefficients, edge samples and histories
 namespace sfm { enum { TAB = 0 /* [send][12] */, EDGE = 24 /* [channel][4]: samples 0, 1, 62, 63 of the tile being filtered */, HIST = 32 /* [row][6] */, SIZE = 64 }; }
 
-template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true, bool SF = false>
+template <int CH, int NW, bool FP = false, bool MD = true, bool ST = true, bool SF = false, int CR = 0>
 struct SteadyShared {
     static constexpr bool MC = CH > 2;
     static constexpr int kMcBase = ut::SIZE + 8 * kRow; // multichannel tables behind the hand-over rows (the modulation row shares the first of
@@ -339,6 +343,7 @@ struct SteadyShared {
     unsigned tapn_all[(FP || MC) ? 1 : NW][24]; // XF: [wave][group * 4 + line]: the taps being faded in, as byte distances like ut::TAP4
     alignas(16) float sf_rows[SF ? NW : 1][SF ? 4 * CH : 1][SF ? kRow : 4]; // SF: [wave][stage * 2 * CH + send * CH + channel]
     float sf_misc[SF ? NW : 1][SF ? sfm::SIZE : 4];
+    alignas(16) float cr_tails[CR == 2 ? NW : 1][CR == 2 ? 5 : 1][CR == 2 ? 32 : 1][4]; // CR == 2: [wave][store site][lane][line]: the tile's samples past the last line boundary
     int sf_all[NW]; // SF: which instances of the group filter their sends in here
     int go_all[NW];
     int eax_all[NW]; // which instances of the group are EAX reverbs (second input shelf)
@@ -358,7 +363,24 @@ __device__ __forceinline__ unsigned this_cu()
     return 0x10000u | ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, class SH>
+// CR (the plain FP builds: every tap three tiles away, early taps and late-line offsets 32 samples more -- kPlainMinTapAhead): ring stores
+// that cover whole 128-byte lines.  A tile's 64 samples of a ring line are 256 contiguous bytes, but where they start is the delay
+// line's write position: after a call that was not a multiple of 32 frames every such store begins and ends inside a line, for the rest
+// of the instance's life, and the late feed's stores (main delay, late_feed_tap samples back: 16012 with the defaults, 12 past a line)
+// never were aligned.  Memory takes a line written in two parts badly (what launches hand on is uncached: no L2 merges the parts):
+// 256-frame calls after one call of 441, 100 or 37 frames took 13 - 21 % longer (profiles/r03n_round3_end/misaligned_ring_positions.txt),
+// and with the stores rounded down to lines, an ablation, nothing of that was left (profiles/r04a_line_aligned_stores/).  So a store
+// site holds back the r samples of its tile that lie past the last line boundary, r = position % 32, and writes them with the next
+// tile's: lane L stores the sample r places before its own (a lane rotation), lanes below r the ones held back -- in a register per
+// value (CR >= 1: the late feed's four, every plain FP build) or in 32 floats of LDS per value (CR == 2: all six sites, the build the
+// host picks when the write position of an instance of the launch is off the grid).  The call's first tile leaves the lanes below r
+// alone (the call before wrote those samples), its last tile writes its held-back samples as well: two partial lines per ring line and
+// call instead of two per tile.  (Measured and dropped: reading the r samples in front of the first tile again, so that the call's
+// first store covers whole lines too -- the wait for them in front of the loop cost more than the partial lines, 45.2 against 44.2 us;
+// and the late feed alone held back in the build for positions on the grid, CR == 1: 41.4 against 40.5 us with the reload, no
+// difference without.)  Loads that reach into the tile before are the reason for kPlainMinTapAhead: a held-back sample is in
+// memory one tile later.
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, int CR = 0, class SH>
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
 {
@@ -624,7 +646,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // shortest distance accepted per group (ST build only)
         // (ST: early and late taps and the early line of any length, all-pass offsets from four samples -- up to fifteen evaluations ahead
         // per tile --, the late line a whole tile: its loop runs through the T60 chain phases)
-        const unsigned shortest = !ST ? (HY ? 256u : (FP ? 4u * kPlainMinTap : 512u)) : (grp == 0 || grp == 2 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 16u : 256u;
+        const unsigned shortest = !ST ? (HY ? 256u : (FP ? 4u * ((grp == 0 || grp == 5) ? kPlainMinTapAhead : kPlainMinTap) : 512u)) : (grp == 0 || grp == 2 || grp == 3) ? 0u : (grp == 1 || grp == 4) ? 16u : 256u;
         if (__ballot(tp >= shortest + feed4 && tpn >= shortest + feed4) != ~0ULL) go = false;
         if (ST) {
             const unsigned long long in_tile = __ballot(lane < 24 && (tp < 256u + feed4 || tpn < 256u + feed4));
@@ -901,6 +923,41 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #endif
         st_ring<r>(slab_b, wp | lo.x, v0); st_ring<r>(slab_b, wp | lo.y, v1); st_ring<r>(slab_b, wp | lo.z, v2); st_ring<r>(slab_b, wp | lo.w, v3);
     };
+    // CR: a store site's tile as whole lines (see the template parameter).  `rot`: lane L holds the value of the sample r places before
+    // its own (lanes below r: of the tile's last r samples); `before`: what those lanes held a tile ago.
+    static_assert(CR == 0 || (AW && !SF && !RG), "line-aligned stores: the plain FP builds");
+    auto cr_lane_before = [&](unsigned r) -> int { return ((lane - static_cast<int>(r)) & 63) << 2; };
+    auto cr_rot = [&](int from4, float v) -> float { return __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(from4, static_cast<int>(__float_as_uint(v))))); };
+    auto carry_store = [&](unsigned tile4, auto ring, unsigned r, const v4f& rot, const v4f& before, bool head, bool tail) {
+        constexpr int rg = decltype(ring)::value;
+        const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * rg);
+        const unsigned bm = utu[ut::BMASK + rg];
+        const bool held = lane < static_cast<int>(r);
+        const unsigned at = tile4 - 4u * r + 4u * static_cast<unsigned>(lane);
+#ifdef OALSFX_CR_ABLATE // timing experiment: no partial lines at the call's ends either (results wrong)
+        head = tail = false;
+#endif
+        if (!(head && held)) { // (the call's first tile: the call before has written what lies in front of it)
+            const unsigned wp = at & bm;
+            st_ring<rg>(slab_b, wp | lo.x, held ? before.x : rot.x); st_ring<rg>(slab_b, wp | lo.y, held ? before.y : rot.y);
+            st_ring<rg>(slab_b, wp | lo.z, held ? before.z : rot.z); st_ring<rg>(slab_b, wp | lo.w, held ? before.w : rot.w);
+        }
+        if (tail && held) { // the call's last tile: nothing comes behind it to take its last samples along
+            const unsigned wp = (at + 256u) & bm;
+            st_ring<rg>(slab_b, wp | lo.x, rot.x); st_ring<rg>(slab_b, wp | lo.y, rot.y); st_ring<rg>(slab_b, wp | lo.z, rot.z); st_ring<rg>(slab_b, wp | lo.w, rot.w);
+        }
+    };
+    // ... held back in LDS (CR == 2): site 0 main delay, 1 early all-pass, 2 early line, 3 late all-pass, 4 late line.  Lane L < r reads
+    // and writes entry L of its values' rows, nobody else's: no hand-over between lanes.
+    auto cr_tail = [&](int site) -> v4f* { return reinterpret_cast<v4f*>(&sh.cr_tails[CR == 2 ? wib : 0][CR == 2 ? site : 0][lane & 31][0]); }; // (one 16-byte record per lane and site)
+    auto carry_store_lds = [&](unsigned tile4, auto ring, int site, const v4f& rot, bool head, bool tail) {
+        v4f* t = cr_tail(site);
+        const unsigned r = utu[ut::CR_R];
+        const v4f before = *t;
+        carry_store(tile4, ring, r, rot, before, head, tail);
+        if (lane < static_cast<int>(r)) *t = rot;
+    };
+    v4f cr_feed = {0, 0, 0, 0}; // CR >= 1: the late feed's values of the tile before, rotated (lanes below r: its last r samples)
     // chain lanes of the chain phases: lane -> (wave cw, line cc) for lane < 4 * NW
     const int cw = (lane >> 2) & (NW - 1), cc = lane & 3;
     float* crowI0 = lds_all[cw] + (0 * 4 + cc) * kRow;
@@ -910,6 +967,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     float* crowL2 = lds_all[cw] + (5 * 4 + cc) * kRow;
     float* cdat = chain_all[cw][cc];
 
+    if (CR != 0 && go) {
+        if (lane == 0) {
+            utu[ut::CR_R] = static_cast<unsigned>(offset) & 31u;
+            utu[ut::CR_RF] = (static_cast<unsigned>(offset) - (utu[ut::FEED4] >> 2)) & 31u;
+        }
+        wave_sync();
+    }
     stamp(); // [2] tables written
     // the first tile's inputs are requested before the workgroup barrier: they travel while the shelves of tile 0 run
     if (go) {
@@ -959,6 +1023,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         const int Lb = RG ? min(64, frames - (tb << 6)) : 64;
         const bool act = RG ? lane < Lb : true;
         const unsigned t4 = static_cast<unsigned>(offset + pos_b) << 2; // the late half's tile
+        const unsigned tile_b4 = static_cast<unsigned>(offset + (tb << 6)) << 2; // ... its first sample (CR)
+        const bool head_b = tb == 0, tail_b = tb == tiles - 1;
         float oa0 = 0.0F, oa1 = 0.0F;
         float outva[MC ? 8 : 1] = {}; // the dry mix (or the running mix of the slots before) of tile ta
         v4f p_e = n_e, p_a = n_a, p_el = n_el, p_lt = n_lt, p_la = n_la, p_ll = n_ll;
@@ -1012,7 +1078,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         v2f e01 = {0, 0}, e23 = {0, 0};
         float dg = 0.0F, ac = 0.0F, sx = 0.0F, sy = 0.0F;
         if (go && has_b) {
-            if (act) store4(t4, RingId<OALSFX_RV_MAIN>{}, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
+            if constexpr (CR == 2) {
+                // (the shelves' output lies in LDS rows: read r places back, no lane rotation)
+                const int from = 4 + (cr_lane_before(utu[ut::CR_R]) >> 2);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_MAIN>{}, 0, v4f{rowI(xg, 0)[from], rowI(xg, 1)[from], rowI(xg, 2)[from], rowI(xg, 3)[from]}, head_b, tail_b);
+            } else if (act) store4(t4, RingId<OALSFX_RV_MAIN>{}, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
             wave_sync();
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
             dg = misc.x; ac = misc.y; sx = misc.z; sy = misc.w;
@@ -1077,7 +1147,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             v2f g01 = f01 + (ac * v01);
             v2f g23 = f23 + (ac * v23);
             scatter2(g01, g23, sx, sy);
-            if (act) {
+            if constexpr (CR == 2) {
+                const int f4 = cr_lane_before(utu[ut::CR_R]);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_AP>{}, 1, v4f{cr_rot(f4, g01.x), cr_rot(f4, g01.y), cr_rot(f4, g23.x), cr_rot(f4, g23.y)}, head_b, tail_b);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_LINE>{}, 2, v4f{cr_rot(f4, v23.y), cr_rot(f4, v23.x), cr_rot(f4, v01.y), cr_rot(f4, v01.x)}, head_b, tail_b);
+            } else if (act) {
                 store4(t4, RingId<OALSFX_RV_EARLY_AP>{}, g01.x, g01.y, g23.x, g23.y);
                 store4(t4, RingId<OALSFX_RV_EARLY_LINE>{}, v23.y, v23.x, v01.y, v01.x);
             }
@@ -1105,7 +1179,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             {
                 v2f r01 = {e23.y, e23.x}, r23 = {e01.y, e01.x};
                 scatter2(r01, r23, sx, sy);
-                if (act) store4(t4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, r01.x, r01.y, r23.x, r23.y);
+                if constexpr (CR >= 1) {
+                    const unsigned rf = utu[ut::CR_RF];
+                    const int f4 = cr_lane_before(rf);
+                    const v4f rot = {cr_rot(f4, r01.x), cr_rot(f4, r01.y), cr_rot(f4, r23.x), cr_rot(f4, r23.y)};
+                    carry_store(tile_b4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, rf, rot, cr_feed, head_b, tail_b);
+                    cr_feed = rot;
+                } else if (act) store4(t4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, r01.x, r01.y, r23.x, r23.y);
                 if (ST && (short_mask & 8u)) {
                     // late taps closer than a tile to the late feed read what an earlier lane just fed
                     strow(4)[4 + lane] = r01.x; strow(5)[4 + lane] = r01.y; strow(6)[4 + lane] = r23.x; strow(7)[4 + lane] = r23.y;
@@ -1429,10 +1509,16 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             const v2f l23 = v2f{p_la.z, p_la.w} - (ac * i23);
             v2f q01 = i01 + (ac * l01), q23 = i23 + (ac * l23);
             scatter2(q01, q23, sx, sy);
-            if (act) store4(t4, RingId<OALSFX_RV_LATE_AP>{}, q01.x, q01.y, q23.x, q23.y);
+            if constexpr (CR == 2) {
+                const int f4 = cr_lane_before(utu[ut::CR_R]);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_AP>{}, 3, v4f{cr_rot(f4, q01.x), cr_rot(f4, q01.y), cr_rot(f4, q23.x), cr_rot(f4, q23.y)}, head_b, tail_b);
+            } else if (act) store4(t4, RingId<OALSFX_RV_LATE_AP>{}, q01.x, q01.y, q23.x, q23.y);
             v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
             scatter2(r01, r23, sx, sy);
-            if (act) store4(t4, RingId<OALSFX_RV_LATE_LINE>{}, r01.x, r01.y, r23.x, r23.y);
+            if constexpr (CR == 2) {
+                const int f4 = cr_lane_before(utu[ut::CR_R]);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_LINE>{}, 4, v4f{cr_rot(f4, r01.x), cr_rot(f4, r01.y), cr_rot(f4, r23.x), cr_rot(f4, r23.y)}, head_b, tail_b);
+            } else if (act) store4(t4, RingId<OALSFX_RV_LATE_LINE>{}, r01.x, r01.y, r23.x, r23.y);
             const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
             if (MC) {
                 // early lines 0..3 then late lines 0..3, each into every audible channel (reference src/oalsfxpp.cpp:6142-6166)
@@ -1635,11 +1721,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     stamp(); // state handed back
 }
 
-template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false>
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, int CR = 0>
 __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
 {
-    __shared__ SteadyShared<CH, NW, FP, MD, ST, SF> sh;
-    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    __shared__ SteadyShared<CH, NW, FP, MD, ST, SF, CR> sh;
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
 }
 
 // One grid for a slot's steady reverbs of several kinds (mono / stereo, whole tiles).  The host orders the slot's list by kind and the
@@ -1652,11 +1738,15 @@ struct SteadyKinds {
     __host__ __device__ int groups(int k) const { return (count[k] + 3) >> 2; }
 };
 
-template <int CH, bool NF, bool SF>
+// (plain FP workgroups of a grid of kinds: the late feed's stores line-aligned unless the send filters are inside, whose LDS leaves no
+// room to choose; CR == 2: every store site, the build for write positions off the line grid)
+constexpr int kCrBase = OALSFX_CR_FEED ? 1 : 0;
+template <int CH, bool NF, bool SF, int CR = (SF ? 0 : kCrBase)>
 __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, int slot, const int* __restrict__ list, SteadyKinds kinds, int flags)
 {
+    static_assert(!SF || CR == 0, "send filters inside and line-aligned stores: no LDS for both");
     union Shared {
-        SteadyShared<CH, 4, true, false, false, SF> lean; // plain and HY (SF: with the send filters inside)
+        SteadyShared<CH, 4, true, false, false, SF, CR> lean; // plain and HY (SF: with the send filters inside)
         SteadyShared<CH, 4, true, true, true> general;   // ST (includes MD)
         SteadyShared<CH, 4, false, true, true> believed; // XF
     };
@@ -1674,7 +1764,7 @@ __global__ __launch_bounds__(256, 4) void k_reverb_steady_kinds(KernelCtx ctx, i
     const int rest = static_cast<int>(blockIdx.x) - slow_groups;
     int group = (flags & kNoCuMajor) ? rest : cu_major_position(rest, static_cast<int>(gridDim.x) - slow_groups);
     if (group < kinds.groups(0)) {
-        reverb_steady_group<CH, 4, false, false, false, false, false, true, false, false, SF>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
+        reverb_steady_group<CH, 4, false, false, false, false, false, true, false, false, SF, CR>(ctx, slot, list, kinds.count[0], flags, group, sh.lean);
         return;
     }
     group -= kinds.groups(0);
@@ -2361,63 +2451,75 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
 
 // Steady instances: the cooperative tile loop.  Believed steady (`proven` false): an instance that turns out not to be (the kernel
 // decides from the device state) falls back to the general path inside the kernel, out of line.  Proven steady: the FP builds.
-// Returns the symbol it launched (as rocprofv3 prints its template arguments), nullptr when there was nothing to launch.
-#define OALSFX_STEADY(...)                                                                                                       \
-    do {                                                                                                                         \
-        OALSFX_LAUNCH((k_reverb_steady_coop<__VA_ARGS__>), grid, block, stream, c, slot, list, count, flags);                    \
-        return "k_reverb_steady_coop<" #__VA_ARGS__ ">";                                                                         \
+// carry: some listed instance's write position is off the 128-byte line grid (an odd-sized call came before): the plain FP build that
+// holds back every store site's tail (CR == 2) instead of the late feed's only.
+// Returns the symbol it launched (every template argument, as rocprofv3 prints them), nullptr when there was nothing to launch.
+// template arguments: channels, wavefronts per workgroup, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR
+#define OALSFX_STEADY(CHv, TLv, HYv, MDv, STv, RGv, FPv, XFv, CRv)                                                                               \
+    do {                                                                                                                                         \
+        OALSFX_LAUNCH((k_reverb_steady_coop<CHv, 4, TLv, HYv, MDv, STv, RGv, FPv, XFv, false, false, CRv>), grid, block, stream, c, slot, list, count, flags); \
+        return "k_reverb_steady_coop<" #CHv ", 4, " #TLv ", " #HYv ", " #MDv ", " #STv ", " #RGv ", " #FPv ", " #XFv ", false, false, " #CRv ">";  \
     } while (0)
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,
-                                 bool proven, bool in_transition, hipStream_t stream, int* groups)
+                                 bool proven, bool in_transition, hipStream_t stream, int* groups, bool carry)
 {
     if (groups) *groups = count > 0 ? (count + 3) / 4 : 0;
     if (count <= 0) return nullptr;
     const dim3 grid((count + 3) / 4), block(256);
     const KernelCtx& c = ctx;
     const bool ragged = (c.frames & 63) != 0; // the call ends in a partial tile: the most general build's ragged variant
-    // template arguments: channels, wavefronts per workgroup, TL, HY, MD, ST, RG, FP
     if (proven && !ragged && c.channels <= 2) {
         // the host has proven every listed instance steady: the builds without steady-state test and general path, started from hot records
         if (c.channels == 1) {
-            if (short_taps) OALSFX_STEADY(1, 4, false, true, true, true, false, true);
-            if (modulated) OALSFX_STEADY(1, 4, false, true, true, false, false, true);
-            if (close_taps) OALSFX_STEADY(1, 4, false, true, false, false, false, true);
-            OALSFX_STEADY(1, 4, false, false, false, false, false, true);
+            if (short_taps) OALSFX_STEADY(1, false, true, true, true, false, true, false, 0);
+            if (modulated) OALSFX_STEADY(1, false, true, true, false, false, true, false, 0);
+            if (close_taps) OALSFX_STEADY(1, false, true, false, false, false, true, false, 0);
+            if (carry) OALSFX_STEADY(1, false, false, false, false, false, true, false, 2);
+#if OALSFX_CR_FEED
+            OALSFX_STEADY(1, false, false, false, false, false, true, false, 1);
+#else
+            OALSFX_STEADY(1, false, false, false, false, false, true, false, 0);
+#endif
         }
-        if (short_taps) OALSFX_STEADY(2, 4, false, true, true, true, false, true);
-        if (modulated) OALSFX_STEADY(2, 4, false, true, true, false, false, true);
-        if (c.timeline && !close_taps) OALSFX_STEADY(2, 4, true, false, false, false, false, true); // (a plain build: no fallback for close taps in an FP launch)
-        if (close_taps) OALSFX_STEADY(2, 4, false, true, false, false, false, true);
-        OALSFX_STEADY(2, 4, false, false, false, false, false, true);
+        if (short_taps) OALSFX_STEADY(2, false, true, true, true, false, true, false, 0);
+        if (modulated) OALSFX_STEADY(2, false, true, true, false, false, true, false, 0);
+        if (c.timeline && !close_taps) OALSFX_STEADY(2, true, false, false, false, false, true, false, 0); // (a plain build: no fallback for close taps in an FP launch)
+        if (close_taps) OALSFX_STEADY(2, false, true, false, false, false, true, false, 0);
+        if (carry) OALSFX_STEADY(2, false, false, false, false, false, true, false, 2);
+#if OALSFX_CR_FEED
+        OALSFX_STEADY(2, false, false, false, false, false, true, false, 1);
+#else
+        OALSFX_STEADY(2, false, false, false, false, false, true, false, 0);
+#endif
     }
     if (c.channels > 2) {
         // multichannel: the most general build only; the caller launches the general kernel on the same list right after
-        if (ragged) OALSFX_STEADY(8, 4, false, true, true, true, true, false);
-        if (short_taps || modulated) OALSFX_STEADY(8, 4, false, true, true, true, false, false);
-        if (close_taps) OALSFX_STEADY(8, 4, false, true, false, false, false, false);
-        OALSFX_STEADY(8, 4, false, false, false, false, false, false);
+        if (ragged) OALSFX_STEADY(8, false, true, true, true, true, false, false, 0);
+        if (short_taps || modulated) OALSFX_STEADY(8, false, true, true, true, false, false, false, 0);
+        if (close_taps) OALSFX_STEADY(8, false, true, false, false, false, false, false, 0);
+        OALSFX_STEADY(8, false, false, false, false, false, false, false, 0);
     }
     if (ragged) {
-        if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, true, false);
-        OALSFX_STEADY(2, 4, false, true, true, true, true, false);
+        if (c.channels == 1) OALSFX_STEADY(1, false, true, true, true, true, false, false, 0);
+        OALSFX_STEADY(2, false, true, true, true, true, false, false, 0);
     }
     if (in_transition) {
         // some listed instance is folding in a property change (cross-fade, gain ramps): the variant of the most general build that
         // keeps such instances in their workgroup instead of sending them down the general path
-        if (c.channels == 1) OALSFX_STEADY(1, 4, false, true, true, true, false, false, true);
-        OALSFX_STEADY(2, 4, false, true, true, true, false, false, true);
+        if (c.channels == 1) OALSFX_STEADY(1, false, true, true, true, false, false, true, 0);
+        OALSFX_STEADY(2, false, true, true, true, false, false, true, 0);
     }
     if (c.channels == 1) {
-        if (short_taps) OALSFX_STEADY(1, 4, false, true, true, true, false, false);
-        if (modulated) OALSFX_STEADY(1, 4, false, true, true, false, false, false);
-        if (close_taps) OALSFX_STEADY(1, 4, false, true, false, false, false, false);
-        OALSFX_STEADY(1, 4, false, false, false, false, false, false);
+        if (short_taps) OALSFX_STEADY(1, false, true, true, true, false, false, false, 0);
+        if (modulated) OALSFX_STEADY(1, false, true, true, false, false, false, false, 0);
+        if (close_taps) OALSFX_STEADY(1, false, true, false, false, false, false, false, 0);
+        OALSFX_STEADY(1, false, false, false, false, false, false, false, 0);
     }
-    if (short_taps) OALSFX_STEADY(2, 4, false, true, true, true, false, false);
-    if (modulated) OALSFX_STEADY(2, 4, false, true, true, false, false, false);
-    if (c.timeline) OALSFX_STEADY(2, 4, true, false, false, false, false, false);
-    if (close_taps) OALSFX_STEADY(2, 4, false, true, false, false, false, false);
-    OALSFX_STEADY(2, 4, false, false, false, false, false, false);
+    if (short_taps) OALSFX_STEADY(2, false, true, true, true, false, false, false, 0);
+    if (modulated) OALSFX_STEADY(2, false, true, true, false, false, false, false, 0);
+    if (c.timeline) OALSFX_STEADY(2, true, false, false, false, false, false, false, 0);
+    if (close_taps) OALSFX_STEADY(2, false, true, false, false, false, false, false, 0);
+    OALSFX_STEADY(2, false, false, false, false, false, false, false, 0);
 }
 #undef OALSFX_STEADY
 
@@ -2425,7 +2527,7 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 // tap of one to two tiles, [2] proven with shorter taps or a modulated late line, [3] believed steady or in a transition the XF build
 // follows; `list` holds them in this order.  One kind alone takes its lean kernel, several share the grid of k_reverb_steady_kinds.
 const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int* list, const int counts[4], int flags, bool no_fallback, bool filters_inside,
-                                       hipStream_t stream, int* groups_out)
+                                       hipStream_t stream, int* groups_out, bool carry)
 {
     const int total = counts[0] + counts[1] + counts[2] + counts[3];
     if (groups_out) *groups_out = total > 0 ? (total + 3) / 4 : 0; // (one kind alone: its lean kernel; the grid of kinds says below what it takes)
@@ -2439,14 +2541,14 @@ const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int
         if (sf) {
             // one of the first two kinds alone, with the send filters inside: template arguments channels, wavefronts, TL, HY, MD, ST, RG, FP, XF, NF, SF
             const dim3 grid((total + 3) / 4), block(256);
-            if (ctx.channels == 1 && only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true>"; }
-            if (ctx.channels == 1) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true>"; }
-            if (only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true>"; }
-            OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true>), grid, block, stream, ctx, slot, list, total, flags);
-            return "k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true>";
+            if (ctx.channels == 1 && only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true, 0>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, false, false, false, false, true, false, false, true, 0>"; }
+            if (ctx.channels == 1) { OALSFX_LAUNCH((k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true, 0>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<1, 4, false, true, false, false, false, true, false, false, true, 0>"; }
+            if (only == 0) { OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true, 0>), grid, block, stream, ctx, slot, list, total, flags); return "k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, true, 0>"; }
+            OALSFX_LAUNCH((k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true, 0>), grid, block, stream, ctx, slot, list, total, flags);
+            return "k_reverb_steady_coop<2, 4, false, true, false, false, false, true, false, false, true, 0>";
         }
         // (close_taps / modulated / short_taps select the FP build of the kind; the believed kind alone: the XF build with the general path inside)
-        return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream, groups_out);
+        return launch_reverb_steady(ctx, slot, list, total, flags, only == 1, false, only == 2, only != 3, only == 3, stream, groups_out, carry && only == 0);
     }
     KernelCtx c = ctx;
     c.list_first = -1; // (the kinds read their entries from the list)
@@ -2460,14 +2562,24 @@ const char* launch_reverb_steady_kinds(const KernelCtx& ctx, int slot, const int
         OALSFX_LAUNCH((k_reverb_steady_kinds<__VA_ARGS__>), grid, block, stream, c, slot, list, kinds, flags); \
         return "k_reverb_steady_kinds<" #__VA_ARGS__ ">";                                                  \
     } while (0)
+    // template arguments: channels, NF, SF, CR (the plain kind's workgroups; see k_reverb_steady_kinds)
+    const bool carry_all = carry && counts[0] > 0 && !sf && !no_fallback;
+#if OALSFX_CR_FEED
+#define OALSFX_KINDS_BASE(CHv, NFv) OALSFX_KINDS(CHv, NFv, false, 1)
+#else
+#define OALSFX_KINDS_BASE(CHv, NFv) OALSFX_KINDS(CHv, NFv, false, 0)
+#endif
     if (c.channels == 1) {
-        if (no_fallback) OALSFX_KINDS(1, true, false);
-        if (sf) OALSFX_KINDS(1, false, true);
-        OALSFX_KINDS(1, false, false);
+        if (no_fallback) OALSFX_KINDS_BASE(1, true);
+        if (sf) OALSFX_KINDS(1, false, true, 0);
+        if (carry_all) OALSFX_KINDS(1, false, false, 2);
+        OALSFX_KINDS_BASE(1, false);
     }
-    if (no_fallback) OALSFX_KINDS(2, true, false);
-    if (sf) OALSFX_KINDS(2, false, true);
-    OALSFX_KINDS(2, false, false);
+    if (no_fallback) OALSFX_KINDS_BASE(2, true);
+    if (sf) OALSFX_KINDS(2, false, true, 0);
+    if (carry_all) OALSFX_KINDS(2, false, false, 2);
+    OALSFX_KINDS_BASE(2, false);
+#undef OALSFX_KINDS_BASE
 #undef OALSFX_KINDS
 }
 

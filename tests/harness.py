@@ -241,9 +241,10 @@ def reverb_params(effect, fmt=desc.FMT_STEREO, rate=48000):
 def steady_build(symbol):
     """What `Batch.last_reverb_kernel` says about the steady-state launch: {'kinds': the grid of several kinds, 'fp': a proven-steady build
     (no steady-state test inside), 'xf': the build that follows property changes}.  Template arguments of k_reverb_steady_coop: channels,
-    wavefronts, TL, HY, MD, ST, RG, FP, XF."""
+    wavefronts, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR ('cr': 2 every ring line written in whole cache lines, the build for write positions off the line grid)."""
     if symbol.startswith("k_reverb_steady_kinds"):
-        return {"kinds": True, "fp": False, "xf": False}
+        args = [a.strip() for a in symbol[symbol.index("<") + 1: symbol.rindex(">")].split(",")]
+        return {"kinds": True, "fp": False, "xf": False, "cr": int(args[3]) if len(args) > 3 else 0}
     args = [a.strip() for a in symbol[symbol.index("<") + 1: symbol.rindex(">")].split(",")]
     flag = lambda k: len(args) > k and args[k] == "true"
-    return {"kinds": False, "fp": flag(7), "xf": flag(8)}
+    return {"kinds": False, "fp": flag(7), "xf": flag(8), "cr": int(args[11]) if len(args) > 11 else 0}

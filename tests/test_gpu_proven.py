@@ -275,3 +275,59 @@ def test_a_broken_host_invariant_is_reported_not_hidden(fmt):
                 b.mix(x)
     finally:
         so.oalsfx_debug_set_flags(0)
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+@pytest.mark.parametrize("first", [441, 100, 37, 16, 8, 31, 33])
+def test_line_aligned_stores_after_an_odd_sized_call(fmt, first):
+    """After a call that is not a multiple of 32 frames the delay lines' write position stands inside a 128-byte line, for good.  The
+    plain proven build then writes every ring line in whole lines: a tile's samples past the last line boundary are held back and
+    written with the next tile's, the call's last tile writes its own too (reverb.hip, CR == 2).  Whole-tile calls of every size after one
+    odd call, more odd calls in between (the position changes: 441 % 32 = 25, then 25 + 100 % 32 = 29, ...), plain presets alone (the
+    lean kernel) -- outputs of every call, then state and delay lines, word for word."""
+    presets = [0, 5, 13, 0, 26, 44, 0, 61, 67]   # (every tap three tiles away: the plain kind)
+    f = Follow(fmt, 48000, 1, [[(0, preset_effect(p, desc.EAX_REVERB if j % 3 else desc.REVERB))] for j, p in enumerate(presets)])
+    try:
+        b = f.b
+        f.mix(256); f.mix(256); f.mix(256)
+        assert steady_build(b.last_reverb_kernel)["fp"] and steady_build(b.last_reverb_kernel)["cr"] == 0, b.last_reverb_kernel
+        f.mix(first)
+        for frames in (256, 256, 64, 128, 2048, 512, 256):
+            f.mix(frames)
+            k = steady_build(b.last_reverb_kernel)
+            assert k["fp"] and k["cr"] == (2 if first % 32 else 0), b.last_reverb_kernel
+        f.check_state()
+        f.mix(100 - first % 32 if first % 32 else 32)    # back on the grid, or another 32 frames along it
+        f.mix(256); f.mix(256)
+        pos = first + (100 - first % 32 if first % 32 else 32)
+        assert steady_build(b.last_reverb_kernel)["cr"] == (2 if pos % 32 else 0), b.last_reverb_kernel
+        f.mix(7); f.mix(256); f.mix(256); f.mix(4096); f.mix(64); f.mix(64)
+        assert steady_build(b.last_reverb_kernel)["cr"] == 2, b.last_reverb_kernel
+        f.check_state()
+    finally:
+        f.close()
+
+
+def test_line_aligned_stores_in_a_grid_of_several_kinds():
+    """The same with plain, close-tap and short-tap presets in one batch (k_reverb_steady_kinds: the plain kind's workgroups hold their
+    stores back, the others write as they always did), one instance restarted later than the rest (its position differs from theirs),
+    and a property change on the way."""
+    presets = [0, 5, 13, 0, 2, 2, 2, 2, 3, 25, 3, 25, 26, 44]
+    f = Follow(desc.FMT_STEREO, 48000, 1, [[(0, preset_effect(p))] for p in presets])
+    try:
+        b = f.b
+        for frames in (256, 256, 441, 256, 256, 256):
+            f.mix(frames)
+        k = steady_build(b.last_reverb_kernel)
+        assert k["kinds"] and k["cr"] == 2, b.last_reverb_kernel
+        b.set_effect_type(0, desc.ECHO, first=1, count=1); f.apply(); f.mix(64)
+        b.set_effect(0, preset_effect(5), first=1, count=1); f.apply()
+        for frames in (256, 256, 23, 256, 256, 256, 128):
+            f.mix(frames)
+        b.set_effect(0, preset_effect(13), first=0, count=1); f.apply()
+        for frames in (256, 256, 256, 256, 64, 1024):
+            f.mix(frames)
+        assert b.plan(0)[1] == len(presets), b.plan(0)
+        f.check_state()
+    finally:
+        f.close()
