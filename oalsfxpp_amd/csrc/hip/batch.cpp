@@ -922,7 +922,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
 // general path inside (experiment: what the fallback's scratch frame costs the grid), 0x200 no send filters inside the steady-state
 // builds (the pre-pass kernel for every filtered instance, as before round 3), 0x400 no chained launches: consecutive calls in plain
-// stream order (bench.py --no-chain), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
+// stream order (bench.py --no-chain), 0x2000 no proven ragged builds (calls that end in a partial tile on the believing build, in stream
+// order: as before round 4), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
 // of tests/test_gpu_chained.py: it must fail).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
 // delay lines, state and hot records live), OALSFX_HOST_PROFILE (what the host spends in prepare_params, printed by synchronize)
@@ -1206,6 +1207,7 @@ bool check_fault(oalsfx_batch* b)
 struct SlotPlan {
     int light, steady, reverbs;
     bool use_steady, mixed, by_kind, proven_usable;
+    bool ragged_proven; // a call that ends in a partial tile, every steady reverb of the slot proven and at rest for its last block: the FP RG builds
 };
 
 SlotPlan plan_slot(const oalsfx_batch* b, const KernelCtx& ctx, int s, int n, bool null_has_duty)
@@ -1219,13 +1221,16 @@ SlotPlan plan_slot(const oalsfx_batch* b, const KernelCtx& ctx, int s, int n, bo
     p.reverbs = b->list_count[s][OALSFX_REVERB] + b->list_count[s][OALSFX_EAX_REVERB];
     // ring-light effects and steady reverbs in the same slot (mono / stereo): one grid serves both
     p.mixed = p.light > 0 && p.steady > 0 && b->channels <= 2 && !ctx.timeline && !(debug_flags() & 0x80000);
-    // (the last block of a whole-tile call is its shortest: 64 .. 256 frames)
-    const int last_block_tiles = (n & 63) == 0 ? (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 : 0;
-    const bool gains_rest = last_block_tiles >= b->rest_tiles[s];
+    // (the last block of a call is its shortest: up to 256 frames; the proven instances' gains are at rest for blocks of rest_tiles tiles
+    // and longer)
+    const int last_block = n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
+    const bool gains_rest = last_block >= 64 * b->rest_tiles[s];
     // (round 3: the proven instances no longer wait for the last believed one of their slot: one grid serves every kind,
     // k_reverb_steady_kinds, each workgroup on the build its instances need)
     p.by_kind = p.use_steady && !p.mixed && b->channels <= 2 && (n & 63) == 0 && !ctx.timeline;
     p.proven_usable = gains_rest && !(debug_flags() & 0x200000);
+    p.ragged_proven = p.use_steady && !p.mixed && b->channels <= 2 && (n & 63) != 0 && !ctx.timeline && p.proven_usable && b->slow_count[s] == 0 &&
+                      b->fast_count[s] > 0 && !(debug_flags() & 0x2000);
     return p;
 }
 
@@ -1269,9 +1274,16 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     if (!b->uncached) return false;
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
-    if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK || (frames & 63) != 0) return false;
+    if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK) return false;
     const int steady = b->fast_count[0] + b->slow_count[0];
     if (steady != b->n || b->general_count[0] != 0) return false;
+    if ((frames & 63) != 0) {
+        // a call that ends in a partial tile chains when its step is one launch of the proven ragged builds (no general path inside, no
+        // send-filter pre-pass in front)
+        KernelCtx ctx{};
+        ctx.frames = frames;
+        if (!plan_slot(b, ctx, 0, frames, true).ragged_proven || b->n_filtered > 0) return false;
+    }
     if (b->n_filtered > 0) {
         // send filters: only when every filtered instance's build has them inside (no pre-pass launch in front of the reverb's)
         KernelCtx ctx{};
@@ -1484,8 +1496,9 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 } else if (g == 2 && by_kind) {
                     launch_reverb_kinds_part(b, ctx, s, flags, proven_usable, filters_inside, gs);
                 } else if (g == 2) {
-                    // ragged calls, more than two channels, the timeline build: one launch of the believing builds for all of them
-                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], steady, false, gs);
+                    // ragged calls, more than two channels, the timeline build: one launch of the believing builds for all of them -- or,
+                    // for a ragged call of proven instances only, of the proven ragged builds
+                    launch_reverb_steady_part(b, ctx, s, flags, b->steady_offset[s], steady, sp.ragged_proven, gs);
                 } else {
                     launch_reverb_general_part(b, !use_steady, ctx, s, flags, gs);
                 }

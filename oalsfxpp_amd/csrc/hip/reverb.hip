@@ -384,7 +384,8 @@ template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, boo
 __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int slot, const int* __restrict__ list, int count, int flags, const int group,
                                                     SH& sh)
 {
-    static_assert(!FP || (CH <= 2 && !RG), "the proven-steady builds: mono / stereo, whole tiles");
+    static_assert(!FP || CH <= 2, "the proven-steady builds: mono / stereo");
+    static_assert(!(FP && RG) || (!SF && CR == 0), "the proven ragged builds: the plain and the most general kind, no extras");
     static_assert(!XF || (CH <= 2 && !RG && !FP && HY && MD && ST), "the cross-fading build: a variant of the most general one, mono / stereo, whole tiles");
     static_assert(!SF || (FP && !MD && !ST && NW == 4), "send filters inside: the FP plain and HY builds");
     constexpr int kSfRows = 2 * CH; // SF: rows per stage = sends (direct, this slot's auxiliary) x input channels
@@ -528,16 +529,17 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // the first tile's frame does not depend on the record (unless the send-filter pre-pass ran): it travels beside it
         if (!(flags & kFiltered)) {
             const float* raw = ctx.raw_src + static_cast<size_t>(inst) * ctx.io_stride;
+            const int fl = RG ? min(lane, frames - 1) : lane; // (a ragged call may be shorter than a tile)
             if (CH == 2) {
                 if (OALSFX_NT & 32) {
-                    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(raw + static_cast<size_t>(lane) * 2));
+                    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(raw + static_cast<size_t>(fl) * 2));
                     early_in0 = v.x; early_in1 = v.y;
                 } else {
-                    const float2 v = *reinterpret_cast<const float2*>(raw + static_cast<size_t>(lane) * 2);
+                    const float2 v = *reinterpret_cast<const float2*>(raw + static_cast<size_t>(fl) * 2);
                     early_in0 = v.x; early_in1 = v.y;
                 }
             } else {
-                early_in0 = raw[lane];
+                early_in0 = raw[fl];
             }
         }
         epoch_now = __builtin_amdgcn_readfirstlane(ctx.inst_epoch[inst]);
@@ -1234,7 +1236,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
 #pragma unroll
             for (int c = 0; c < (MC ? 8 : 1); ++c) { inv[c] = n_inv[c]; winv[c] = filtered ? n_wv[c] : n_inv[c]; }
             if (!(SF && sf) && ta + 1 < tiles) issue_input(pos_a + 64); // the next tile's frame, now that this one's is in `in`
-            if (FP && !(SF && sf) && ta + 1 == tiles) {
+            if (FP && !RG && !(SF && sf) && ta + 1 == tiles) {
                 // the call's last two frames, for the histories of the pass-through send filters (no loads in the epilogue)
 #pragma unroll
                 for (int c = 0; c < (MC ? 0 : CH); ++c) {
@@ -1671,7 +1673,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     SGs.hp[at][c] = hp;
                 }
             }
-        } else if (FP) {
+        } else if (FP && !RG) {
             if (first && !filtered && lane < nch)
                 send_history_follow_values(ctx, inst, lane, send_mask, lane == 0 ? hist_new[0] : hist_new[CH - 1], lane == 0 ? hist_old[0] : hist_old[CH - 1]);
         } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
@@ -2491,6 +2493,16 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
 #else
         OALSFX_STEADY(2, false, false, false, false, false, true, false, 0);
 #endif
+    }
+    if (proven && ragged && c.channels <= 2) {
+        // a call that ends in a partial tile, every listed instance proven steady and its gains at rest for the call's last block: the
+        // ragged variants of the plain and of the most general proven build (hot records, no steady-state test, no general path inside)
+        if (c.channels == 1) {
+            if (short_taps || modulated || close_taps) OALSFX_STEADY(1, false, true, true, true, true, true, false, 0);
+            OALSFX_STEADY(1, false, false, false, false, true, true, false, 0);
+        }
+        if (short_taps || modulated || close_taps) OALSFX_STEADY(2, false, true, true, true, true, true, false, 0);
+        OALSFX_STEADY(2, false, false, false, false, true, true, false, 0);
     }
     if (c.channels > 2) {
         // multichannel: the most general build only; the caller launches the general kernel on the same list right after

@@ -244,7 +244,7 @@ def steady_build(symbol):
     wavefronts, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR ('cr': 2 every ring line written in whole cache lines, the build for write positions off the line grid)."""
     if symbol.startswith("k_reverb_steady_kinds"):
         args = [a.strip() for a in symbol[symbol.index("<") + 1: symbol.rindex(">")].split(",")]
-        return {"kinds": True, "fp": False, "xf": False, "cr": int(args[3]) if len(args) > 3 else 0}
+        return {"kinds": True, "fp": False, "xf": False, "rg": False, "cr": int(args[3]) if len(args) > 3 else 0}
     args = [a.strip() for a in symbol[symbol.index("<") + 1: symbol.rindex(">")].split(",")]
     flag = lambda k: len(args) > k and args[k] == "true"
-    return {"kinds": False, "fp": flag(7), "xf": flag(8), "cr": int(args[11]) if len(args) > 11 else 0}
+    return {"kinds": False, "fp": flag(7), "xf": flag(8), "rg": flag(6), "cr": int(args[11]) if len(args) > 11 else 0}

@@ -202,7 +202,7 @@ def test_a_run_that_starts_behind_a_full_queue():
                 s.oracle.mix(warm[0])
         before = b.chained_calls
         run_device_calls(b, [3000, 3000] + [256] * 12 + [3000] + [256] * 12 + [1000] + [128] * 12, shadows, 8000)
-        assert b.chained_calls - before == 36
+        assert b.chained_calls - before == 37   # (12 + 12 + 12 and, since round 4, the ragged 1000-frame call: one launch of the proven ragged build)
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"instance {i}: " + "; ".join(d[:12])
@@ -523,6 +523,57 @@ def test_the_gate_counts_of_host_and_device_agree_over_a_long_run_of_several_kin
         # (the host hands a kind's incomplete workgroup on to the next kind -- steady_kind_counts, batch.cpp -- so today's grids hold
         # exactly a quarter of the instances, rounded up; the count is the launcher's all the same, whatever a later grid looks like)
         assert (h1 - h0) % (1 << 32) >= (b.chained_calls - before) * ((n + 3) // 4)
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_ragged_calls_inside_a_run(fmt):
+    """Calls that end in a partial tile no longer end a run: with every instance proven and at rest for the call's last block, such a
+    call is one launch of the proven ragged builds and chains like a call of whole tiles (441-frame and 480-frame streams: 10 ms
+    buffers).  After the first such call the delay lines' write positions are off the cache-line grid, so the whole-tile calls of the
+    run take the line-aligned store build: both are among what the launches hand on.  Every output buffer, then state and delay lines."""
+    n = 72
+    with Batch(n, fmt, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((0, 5, 13, 26)[i % 4], desc.EAX_REVERB if i % 3 else desc.REVERB) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 2, 3, 35, 36, 70, 71)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        script = [256, 256] + [441] * 12 + [256] * 4 + [480] * 9 + [256, 100, 256, 65, 2047, 256, 441, 441, 512, 128, 64, 480, 256, 256]
+        before = b.chained_calls
+        run_device_calls(b, script, shadows, 23000)
+        assert b.chained_calls - before == len(script), (b.chained_calls - before, len(script))
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+def test_ragged_calls_inside_a_run_at_full_size():
+    """The same with every workgroup slot of the chip taken: 4096 instances of several kinds of presets (the most general proven ragged
+    build), 441-frame calls, a dozen instances followed through every buffer."""
+    n = 4096
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect(i % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 2, 3, 23, 112, 113, 1000, 2047, 2048, 3333, 4094, 4095)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        script = [441] * 40 + [256] * 6 + [480] * 10
+        before = b.chained_calls
+        run_device_calls(b, script, shadows, 24000, replicas=False)
+        assert b.chained_calls - before == len(script), (b.chained_calls - before, len(script))
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"instance {i}: " + "; ".join(d[:12])

@@ -65,8 +65,13 @@ def test_promotion_demotion_and_record_invalidation(fmt):
         f.mix(256)                                        # records built from the descriptors
         assert steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
         f.mix(256); f.mix(64); f.mix(2048); f.mix(4096)  # record hits, every whole-tile call size, several chunks per call
-        # a ragged call runs on the believing build and moves the delay-line positions: the records' stamps no longer match
+        # a ragged call whose last block is as long as a tile runs on the proven ragged build (round 4) and leaves a record for the next call
         f.mix(100)
+        assert steady_build(b.last_reverb_kernel)["fp"] and steady_build(b.last_reverb_kernel)["rg"], b.last_reverb_kernel
+        f.mix(256); f.mix(256)
+        assert steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
+        # a shorter one runs on the believing build and moves the delay-line positions: the records' stamps no longer match
+        f.mix(37)
         assert not steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
         f.mix(256); f.mix(256)
         assert steady_build(b.last_reverb_kernel)["fp"], b.last_reverb_kernel
@@ -328,6 +333,40 @@ def test_line_aligned_stores_in_a_grid_of_several_kinds():
         for frames in (256, 256, 256, 256, 64, 1024):
             f.mix(frames)
         assert b.plan(0)[1] == len(presets), b.plan(0)
+        f.check_state()
+    finally:
+        f.close()
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+@pytest.mark.parametrize("kind", ["plain", "mixed"])
+def test_ragged_calls_on_the_proven_builds(fmt, kind):
+    """Calls that are not a whole number of tiles (441 and 480 frames are 10 ms at 44.1 and 48 kHz) used to run every instance on the
+    believing build, with its steady-state test and the general path inside, and left the hot records stale.  Proven instances whose
+    gains are at rest for the call's last block (frames % 256, or 256) now take the ragged variants of the proven builds: the plain
+    one when every instance is of the plain kind, else the most general.  A last block shorter than a tile (1, 37, 63 frames; 300 = 256 +
+    44) is shorter than any block the device has vouched for: those calls stay on the believing build."""
+    presets = [0, 5, 13, 0, 26, 44, 0, 61, 67] if kind == "plain" else [0, 2, 3, 25, 23, 5, 24, 2, 0, 13]
+    f = Follow(fmt, 48000, 1, [[(0, preset_effect(p, desc.EAX_REVERB if j % 3 else desc.REVERB))] for j, p in enumerate(presets)])
+    try:
+        b = f.b
+        f.mix(256); f.mix(256); f.mix(256)
+        assert b.plan(0)[1] == len(presets), b.plan(0)
+        for frames in (441, 441, 480, 480, 256, 100, 65, 64, 127, 2047, 4095, 441, 256, 256):
+            f.mix(frames)
+            k = steady_build(b.last_reverb_kernel)
+            if frames % 64:
+                assert k["fp"] and k["rg"], (frames, b.last_reverb_kernel)
+                hy = b.last_reverb_kernel.split(",")[3].strip() == "true"
+                assert hy == (kind == "mixed"), (frames, b.last_reverb_kernel)
+            assert b.plan(0)[1] == len(presets), (frames, b.plan(0))
+        f.check_state()
+        for frames in (300, 37, 256, 1, 63, 256, 441):
+            f.mix(frames)
+            k = steady_build(b.last_reverb_kernel)
+            last_block = frames - ((frames - 1) // 256) * 256
+            if frames % 64:
+                assert k["rg"] and k["fp"] == (last_block >= 64), (frames, b.last_reverb_kernel)
         f.check_state()
     finally:
         f.close()
