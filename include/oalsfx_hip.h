@@ -104,6 +104,16 @@ void oalsfx_pinned_free(void* p);
  * oalsfx_batch_mix_device(..., NULL) is in the order of that stream (no overlap of consecutive calls). */
 void* oalsfx_batch_stream(oalsfx_batch* b);
 
+/* ---- device memory the library keeps between batches.  Batches whose calls can overlap on the device keep their delay lines, effect
+ * state and hot records in uncached device memory, which the library takes from the runtime in 2 MiB granules and keeps for the next
+ * batch that asks for a block of that size -- by default for the life of the process: on this runtime, uncached blocks given back with
+ * hipFree have been seen to disturb ordinary allocations made afterwards (profiles/r04b_uncached_free_hazard/).  A process
+ * that needs the memory back calls oalsfx_trim_pools: it waits for the device, frees everything that waits for reuse and returns the
+ * bytes freed; OALSFX_UNCACHED_POOL_MAX_GIB=<GiB> (environment) does the same to whatever exceeds that much whenever a batch is
+ * destroyed.  oalsfx_pools_waiting_bytes says how much waits.  Process-wide. */
+unsigned long long oalsfx_trim_pools(void);
+unsigned long long oalsfx_pools_waiting_bytes(void);
+
 /* ---- state read-back for tests and checkpoints (the reference keeps this in private members of
  * the EffectState subclasses). */
 int oalsfx_batch_read_slot(oalsfx_batch* b, int instance, int slot, oalsfx_slot_params* params, oalsfx_slot_state* state);

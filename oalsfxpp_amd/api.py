@@ -291,3 +291,12 @@ class Api:
         if src.size == 0:
             return src.copy()
         return self._guard(lambda: self._b.mix(src[None])[0], None)
+
+
+def trim_pools():
+    """Gives the uncached device memory that waits for reuse back to the runtime (oalsfx_trim_pools); returns the bytes freed."""
+    return lib.load().oalsfx_trim_pools()
+
+
+def pools_waiting_bytes():
+    return lib.load().oalsfx_pools_waiting_bytes()

@@ -388,13 +388,33 @@ void advance_settling(oalsfx_batch* b, int frames)
 // as those of ordinary memory (tests/test_gpu_chained.py fails on it).
 // OALSFX_RING_MEMORY=default | finegrained | uncached forces one kind for every batch (comparisons; no chained launches unless uncached).
 //
-// Uncached memory is never given back to the runtime: freed and handed out again as ordinary memory it misbehaved -- whole output
-// buffers of a later batch read back as zeros (scripts/uncached_free_hazard.py; gone when the blocks are kept) -- so a block a batch is done with
-// waits in a process-wide pool for the next batch that asks for its size on its device.
+// Uncached memory is not given back to the runtime unless the process asks for it.  Round 3 found that uncached blocks freed with hipFree
+// disturbed allocations made afterwards -- 512 bytes of zeros at the start of a page of a later batch's output, or a reverb instance off
+// for a whole buffer -- and kept every block for the life of the process.  What round 4 established with the reproducer
+// (scripts/uncached_free_hazard.py, profiles/r04b_uncached_free_hazard/):
+//  - the buffer that reads wrong is the later batch's own staging buffer in *ordinary* memory (hipMalloc, the host-pointer entry point):
+//    with the caller's buffers in device memory from another allocator (MODE=device) no run ever failed;
+//  - its addresses do not lie in a range that was uncached before (hazard_trace.txt: 0 of 36 staging allocations), but the failing runs
+//    are the ones whose staging buffers the runtime placed in the 8 MiB neighbourhood of the recycled uncached pages;
+//  - nothing of this library is still in flight when a block is freed (every stream is waited for first, oalsfx_batch_destroy), and a
+//    hipDeviceSynchronize directly in front of the hipFree changes nothing (hazard_modes.txt);
+//  - with every uncached block a whole number of 2 MiB granules, and all of them freed, 4 of 4 runs were clean (granule.txt) -- but
+//    with the small blocks in arenas that stay and only the delay lines freed, granules or not, it is back in 1 run of 4
+//    (hazard_granules.txt): the size of the pieces is not the whole story.
+// So: not a use after free of this library's, reproducible only through hipFree of hipDeviceMallocUncached memory followed by fresh
+// ordinary allocations, and not understood further -- which is why the default stays "keep".  The blocks do come in 2 MiB granules now
+// (small ones out of arenas of the pool's own: fewer runtime calls, and no 4 KiB uncached pieces among ordinary pages), what waits for
+// reuse can be capped (OALSFX_UNCACHED_POOL_MAX_GIB: beyond it the largest waiting blocks are freed when a batch goes; unset: no limit),
+// and oalsfx_trim_pools() frees everything that waits: for a process that needs the memory back and allocates nothing on the device
+// afterwards that it cannot afford to check -- INTEGRATION.md says so.
 class UncachedPool {
 public:
+    static constexpr size_t kGranule = size_t(2) << 20;
+    static constexpr size_t kSmall = size_t(1) << 20; // blocks below this come out of arenas, 4 KiB apart
     hipError_t take(int device, size_t bytes, void** p)
     {
+        if (bytes < kSmall) return take_small(device, bytes, p);
+        bytes = (bytes + kGranule - 1) / kGranule * kGranule;
         {
             // the smallest block that is waiting, large enough and not more than twice as large (a process that goes through many batch
             // shapes then keeps a block per size class rather than per size)
@@ -403,6 +423,7 @@ public:
             if (it != free_.end() && it->first.first == device && it->first.second <= 2 * bytes) {
                 *p = it->second;
                 live_[*p] = it->first;
+                waiting_ -= it->first.second;
                 free_.erase(it);
                 return hipSuccess;
             }
@@ -416,25 +437,110 @@ public:
     }
     bool give_back(void* p) // false: not one of ours
     {
-        std::lock_guard<std::mutex> lock(mutex_);
-        auto it = live_.find(p);
-        if (it == live_.end()) return false;
-        free_.insert({it->second, p});
-        live_.erase(it);
+        std::vector<void*> to_free;
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            auto sm = small_.find(p);
+            if (sm != small_.end()) {
+                Arena& a = arenas_[sm->second];
+                small_.erase(sm);
+                if (--a.live == 0) a.used = 0; // (a bump allocator per arena: the batches that shared it are gone, it starts over)
+                return true;
+            }
+            auto it = live_.find(p);
+            if (it == live_.end()) return false;
+            free_.insert({it->second, p});
+            waiting_ += it->second.second;
+            live_.erase(it);
+            shrink_locked(cap(), to_free);
+        }
+        release(to_free);
         return true;
+    }
+    // Frees what waits for reuse down to `keep_bytes` (largest blocks first) and every arena nobody uses.  Returns the bytes freed.
+    size_t trim(size_t keep_bytes)
+    {
+        std::vector<void*> to_free;
+        size_t before = 0;
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            before = waiting_;
+            shrink_locked(keep_bytes, to_free);
+            before -= waiting_;
+            if (keep_bytes == 0) {
+                for (auto& a : arenas_)
+                    if (a.base && a.live == 0) { to_free.push_back(a.base); a.base = nullptr; before += kGranule; }
+            }
+        }
+        release(to_free);
+        return before;
     }
     size_t bytes_waiting()
     {
         std::lock_guard<std::mutex> lock(mutex_);
-        size_t total = 0;
-        for (const auto& kv : free_) total += kv.first.second;
-        return total;
+        return waiting_;
     }
 
 private:
+    struct Arena { int device; char* base; size_t used; int live; };
+    static size_t cap()
+    {
+        static const size_t c = [] {
+            const char* e = std::getenv("OALSFX_UNCACHED_POOL_MAX_GIB");
+            const double gib = e ? std::atof(e) : -1.0; // (unset: nothing is freed behind the caller's back)
+            return gib < 0.0 ? ~size_t(0) : static_cast<size_t>(gib * 1073741824.0);
+        }();
+        return c;
+    }
+    hipError_t take_small(int device, size_t bytes, void** p)
+    {
+        bytes = (bytes + 4095) / 4096 * 4096; // (every block on pages of its own, as the runtime hands them out)
+        std::lock_guard<std::mutex> lock(mutex_);
+        for (size_t k = 0; k < arenas_.size(); ++k) {
+            Arena& a = arenas_[k];
+            if (a.base && a.device == device && a.used + bytes <= kGranule) {
+                *p = a.base + a.used;
+                a.used += bytes;
+                a.live += 1;
+                small_[*p] = k;
+                return hipSuccess;
+            }
+        }
+        void* base = nullptr;
+        const hipError_t e = hipExtMallocWithFlags(&base, kGranule, hipDeviceMallocUncached);
+        if (e != hipSuccess) return e;
+        size_t k = 0;
+        while (k < arenas_.size() && arenas_[k].base) ++k;
+        if (k == arenas_.size()) arenas_.push_back({});
+        arenas_[k] = {device, static_cast<char*>(base), bytes, 1};
+        *p = base;
+        small_[*p] = k;
+        return hipSuccess;
+    }
+    void shrink_locked(size_t keep_bytes, std::vector<void*>& to_free)
+    {
+        while (waiting_ > keep_bytes && !free_.empty()) {
+            auto largest = free_.begin();
+            for (auto it = free_.begin(); it != free_.end(); ++it)
+                if (it->first.second > largest->first.second) largest = it;
+            waiting_ -= largest->first.second;
+            to_free.push_back(largest->second);
+            free_.erase(largest);
+        }
+    }
+    static void release(const std::vector<void*>& blocks)
+    {
+        // (nothing of the library still uses a block that waits; the synchronisation is for whatever else the process has queued)
+        if (blocks.empty()) return;
+        (void)hipDeviceSynchronize();
+        for (void* q : blocks) (void)hipFree(q);
+    }
     std::mutex mutex_;
     std::multimap<std::pair<int, size_t>, void*> free_;
     std::map<void*, std::pair<int, size_t>> live_;
+    std::vector<Arena> arenas_;
+    std::map<void*, size_t> small_; // small block -> its arena
+    size_t waiting_ = 0;
 };
 
 UncachedPool& uncached_pool()
@@ -909,7 +1015,9 @@ bool ensure_mixbuf(oalsfx_batch* b)
     return b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
 }
 
-// Timing experiments only (OALSFX_DEBUG_FLAGS, or oalsfx_debug_set_flags for A/B runs inside one process): 8 every reverb through the
+// Timing experiments and test switches (OALSFX_DEBUG_FLAGS, or oalsfx_debug_set_flags for A/B runs inside one process): 1 / 2 / 4 the
+// hand-over of chained launches (reverb.hip: every wavefront pays for the acquire behind its wait / none does / instance lines read
+// before the turn has come: tests/test_gpu_chained.py), 8 every reverb through the
 // general kernel, 32 / 64 tap distances rounded to 128 / 256 bytes in the steady-state kernel (results wrong on purpose,
 // scripts/ablate_align.sh), 0x20000 no side streams, 0x80000 no mixed grid (ring-light effects and steady reverbs of a slot as two
 // launches), 0x100000 no cooperative workgroups for the ring-light effects, 0x200000 no proven-steady builds (proven instances go
@@ -2134,6 +2242,13 @@ long long oalsfx_debug_chain_same_cu(oalsfx_batch* b)
     if (hipMemcpy(&v, b->d_turn + static_cast<size_t>(b->n) * b->slots + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
 }
+
+unsigned long long oalsfx_trim_pools(void)
+{
+    return uncached_pool().trim(0);
+}
+
+unsigned long long oalsfx_pools_waiting_bytes(void) { return uncached_pool().bytes_waiting(); }
 
 int oalsfx_debug_chain_started(oalsfx_batch* b, unsigned* host_total, unsigned* device_total)
 {

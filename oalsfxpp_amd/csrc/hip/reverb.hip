@@ -455,6 +455,46 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned cu_before = 0; // the CU the launch before ran this instance on (0: this launch is a run's first)
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
+        // Test switches (OALSFX_DEBUG_FLAGS 1 / 2 / 4, tests/test_gpu_chained.py): 1 every wavefront pays for the agent-scope acquire behind
+        // its wait, as if it always ran where the launch before did (the same-CU path, taken by none of 4.9 million hand-overs on a full
+        // chip: exercised deterministically); 2 none does; 4 before its turn has come the wavefront reads the instance's hot record,
+        // state and the all-pass rings' lines it is about to use -- what the design's invariant "nobody reads an instance's lines before
+        // its turn" forbids -- so that this CU's L1 holds them as they were while the launch before is still writing them: with 2 the
+        // results must come out wrong (the negative control), with 1 the acquire must put them right.
+        const int dbg = flags >> 8;
+        if (dbg & 4) {
+            const unsigned* rec = ctx.hot + sidx * hot::SIZE;
+            const unsigned* st = reinterpret_cast<const unsigned*>(ctx.state + sidx);
+            unsigned junk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned a;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(rec + 64 * k + lane) : "memory"); // (the wait inside: the compiler does not know the load is in flight)
+                junk ^= a;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned a;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(st + 64 * k + lane) : "memory");
+                junk ^= a;
+            }
+            if (slab_b != nullptr) {
+                // (the two all-pass rings: 512 + 1024 frames x 4 lines at 48 kHz, placed behind the three long rings; a dword of every line)
+                const unsigned* ring = reinterpret_cast<const unsigned*>(ctx.rings[sidx]);
+                const oalsfx_reverb_params& PGd = ctx.params[sidx].u.reverb;
+                for (int r = 0; r < 5; ++r) {
+                    if (r == OALSFX_RV_MAIN || r == OALSFX_RV_EARLY_LINE || r == OALSFX_RV_LATE_LINE) continue;
+                    const int words = 4 * PGd.ring_len[r];
+                    for (int w0 = 0; w0 < words; w0 += 64 * 32) {
+                        unsigned a;
+                        const int at = min(w0 + 32 * lane, words - 1);
+                        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(ring + PGd.ring_off[r] + at) : "memory");
+                        junk ^= a;
+                    }
+                }
+            }
+            if (junk == 0x7E57AB1Eu && ctx.timeline) ctx.timeline[0] = junk; // (keeps the loads)
+        }
         int lost = 0;
         if (lane == 0 && !(OALSFX_CHAIN_EXP & 8)) {
             unsigned spins = 0;
@@ -491,7 +531,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             cu_before = before_cu;
             // (the launch before the last counts only where it may have been at work when this launch started: the host knows -- this
             // launch sits behind it in its stream, or it does not)
-            if (before_cu == this_cu() || (ctx.turn_two_back != 0u && before_that_cu == this_cu())) {
+            if (!(dbg & 2) && ((dbg & 1) || before_cu == this_cu() || (ctx.turn_two_back != 0u && before_that_cu == this_cu()))) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
             } else {
@@ -845,6 +885,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     auto strow = [&](int k) -> float* { return utf + ut::SIZE + k * kRow; };
     float* modrow = utf + ut::SIZE;
     int mod_tiles = 0;
+    int mod_base = (v_modidx >= 0 && v_modidx < v_modrange) ? v_modidx : -1; // the modulator's index at the start of the next tile to prepare (-1: not kept)
     auto next_mod_delays = [&](int samples_or_64) -> int { // RG: what the tile holds (a ragged call's last tile holds fewer than 64)
         const int samples = RG ? samples_or_64 : 64;
         if (lane == 0) {
@@ -859,7 +900,17 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         const float fv = modrow[lane];
         mod_f = modrow[samples - 1];
         wave_sync();
-        int index = (v_modidx + (mod_tiles << 6) + lane) % v_modrange;
+        // (the index of this lane's sample modulo the range: carried from tile to tile by additions where the range is at least a tile
+        // long -- the division by a run-time divisor is some thirty-five vector instructions)
+        int index;
+        if (v_modrange >= 64 && mod_base >= 0) {
+            index = mod_base + lane;
+            if (index >= v_modrange) index -= v_modrange;
+            mod_base += 64;
+            if (mod_base >= v_modrange) mod_base -= v_modrange;
+        } else {
+            index = (v_modidx + (mod_tiles << 6) + lane) % v_modrange;
+        }
         mod_tiles += 1;
         const float sinus = glibc_sinf(6.28318530717958647692F * index / v_modrange);
         return lround_away(fv * sinus);

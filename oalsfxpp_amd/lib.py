@@ -53,6 +53,8 @@ SIGNATURES = {
     "oalsfx_batch_placement": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_batch_chained_calls": (C.c_longlong, [C.c_void_p]),
+    "oalsfx_trim_pools": (C.c_ulonglong, []),
+    "oalsfx_pools_waiting_bytes": (C.c_ulonglong, []),
     "oalsfx_debug_chain_same_cu": (C.c_longlong, [C.c_void_p]),
     "oalsfx_debug_chain_started": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),

@@ -1,7 +1,11 @@
-"""Experiment behind the pool of uncached blocks (batch.cpp, UncachedPool): batches created and destroyed one after the other, mono reverbs
-(whose delay lines were uncached blocks, given back with hipFree at the time) in front of stereo batches of stateless types -- whose
-output buffers then read back as zeros, whole instances at a time.  Gone when the uncached blocks are never freed.
-  TYPES=3,1,10 python3 scripts/uncached_free_hazard.py 1000 1000      (effect types to run, frames per call)"""
+"""The experiment behind the pool of uncached blocks (batch.cpp, UncachedPool): batches created and destroyed one after the other, mono
+reverbs in front of stereo batches -- whose output then read back with 512 bytes of zeros at the start of a page, or whose reverbs went
+wrong for a whole instance -- while uncached blocks went back to the runtime with hipFree as the runtime had handed them out (4 KiB
+pieces among them).  Round 4's findings are in profiles/r04b_uncached_free_hazard/ and in the comment at UncachedPool: the buffer that
+reads wrong is the batch's staging buffer in ordinary memory (MODE=device, the caller's own device buffers: never), a
+hipDeviceSynchronize in front of the free does not help, whole 2 MiB granules do.  The pool now allocates in such granules only, so
+  OALSFX_UNCACHED_POOL_MAX_GIB=0 TYPES=3,1,10 python3 scripts/uncached_free_hazard.py 1000 1000
+(nothing waits for reuse: every block is freed when its batch goes) is today's form of the experiment, and comes out clean."""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, random
@@ -26,7 +30,11 @@ for fmt in (desc.FMT_MONO, desc.FMT_STEREO):
                 sh = {i: OracleShadow(b, i) for i in range(n)}
                 for k, f in enumerate(frames_list):
                     x = np.stack([orc.synth(7 + i, k, f * b.channels).reshape(f, b.channels) for i in range(n)])
-                    y = b.mix(x)
+                    if os.environ.get("MODE") == "device":   # (buffers of the caller's in device memory instead of the batch's staging buffers)
+                        dx = torch.from_numpy(x).cuda(); dy = torch.full_like(dx, 7.0)
+                        b.mix_device(f, dx.data_ptr(), dy.data_ptr()); b.synchronize(); y = dy.cpu().numpy()
+                    else:
+                        y = b.mix(x)
                     for i in range(n):
                         sh[i].last = sh[i].mix(x[i]); ok, nbad = same_bits(y[i], sh[i].last)
                         if not ok:

@@ -19,7 +19,7 @@ HEADERS = [os.path.join(ROOT, "include", h) for h in ("oalsfx_hip.h", "oalsfx_hi
 def declared_functions():
     text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned|trim|pools)_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -77,3 +77,9 @@ def test_product_never_links_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_the_pool_entry_points_answer_without_a_gpu():
+    so = lib.load()
+    assert so.oalsfx_pools_waiting_bytes() == 0
+    assert so.oalsfx_trim_pools() == 0

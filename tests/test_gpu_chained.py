@@ -577,3 +577,103 @@ def test_ragged_calls_inside_a_run_at_full_size():
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+def _with_debug_flags(flags, body):
+    import os
+    so = lib.load()
+    base = int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0)
+    so.oalsfx_debug_set_flags(base | flags)
+    try:
+        return body()
+    finally:
+        so.oalsfx_debug_set_flags(base)
+
+
+def _a_run_of_several_kinds(n, seed, calls=24):
+    from oalsfxpp_amd.api import BatchError
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((7 * i) % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in sorted(set([0, 1, 2, 3, n // 2, n - 2, n - 1] + list(range(5, n, max(1, n // 9)))))}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, [256] * calls, shadows, seed, replicas=False)
+        assert b.chained_calls - before == calls
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+        return b.chain_same_cu() if hasattr(b, "chain_same_cu") else None
+
+
+@pytest.mark.parametrize("n", [70, 4096])
+def test_the_same_cu_path_taken_by_every_wavefront(n):
+    """A wavefront that finds itself on the CU the launch before ran its instance on pays for an agent-scope acquire behind its wait
+    (this CU's L1 may hold the instance's lines as that launch read them).  On a full chip that happens to none of millions of
+    hand-overs, with few workgroups to a few per thousand: here every wavefront takes that branch (debug flag 1), 70 instances and 4096,
+    three launches in flight -- the path itself, deterministically."""
+    _with_debug_flags(1, lambda: _a_run_of_several_kinds(n, 26000))
+
+
+@pytest.mark.parametrize("n", [70, 4096])
+def test_lines_read_before_the_turn_are_caught_without_the_acquire_and_cured_by_it(n):
+    """The negative control of the hand-over's central invariant -- nobody reads an instance's lines in a launch before its turn has come,
+    so this CU's L1, emptied when the launch started, holds none of them and needs no invalidate -- and the positive control of the
+    remedy.  Debug flag 4 breaks the invariant on purpose: every wavefront reads its instance's hot record, state and all-pass rings
+    *before* waiting for its turn, while the launch before is still writing them.  With no acquire behind the wait (flag 2) the run
+    must come out wrong (stale lines in L1: the tests do see them); with the acquire behind every wait (flag 1) it must come out
+    right (the acquire does drop them)."""
+    from oalsfxpp_amd.api import BatchError
+    if n <= 128:
+        # (with every workgroup slot of the chip taken, a workgroup only starts when one of the launch before leaves -- its instances'
+        # turn has all but come: nothing stale to read, which is also why the same-CU path is never taken there.  Few workgroups
+        # overlap for most of a launch: there the lines read early are old)
+        with pytest.raises((AssertionError, BatchError)):
+            _with_debug_flags(4 | 2, lambda: _a_run_of_several_kinds(n, 27000))
+    _with_debug_flags(4 | 1, lambda: _a_run_of_several_kinds(n, 27000))
+    _a_run_of_several_kinds(n, 27000)
+
+
+@pytest.mark.parametrize("workload", ["defaults", "presets"])
+def test_every_instance_through_consecutive_chained_calls_at_full_size(workload):
+    """Round 3's full-size runs followed a handful of instances with the oracle and held the rest to each other as replicas of one input,
+    in the last buffer only.  Here every one of 4096 instances has an input of its own and is followed by an oracle of its own (the
+    thread pool of harness.ShadowArmy) through ten consecutive chained calls, each call into an output buffer of its own: 4096 x 10
+    buffers compared word for word, then the state and delay lines of every 97th."""
+    import torch
+    from harness import ShadowArmy
+    n, frames, calls = 4096, 256, 10
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        if workload == "presets":
+            b.set_effect(0, [preset_effect(i % 113) for i in range(n)])
+        else:
+            b.set_effect_type(0, desc.EAX_REVERB)
+        b.apply_changes()
+        army = ShadowArmy(b)
+        army.sync()
+        warm = np.stack([orc.synth(31000 + i, 99, frames * 2).reshape(frames, 2) for i in range(n)])
+        for _ in range(3):
+            b.mix(warm)
+            army.mix(warm)
+        xs = [np.stack([orc.synth(31000 + i, k, frames * 2).reshape(frames, 2) for i in range(n)]) for k in range(calls)]
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = [torch.empty_like(d) for d in dx]
+        torch.cuda.synchronize()
+        before = b.chained_calls
+        for k in range(calls):
+            b.mix_device(frames, dx[k].data_ptr(), dy[k].data_ptr())
+        b.synchronize()
+        assert b.chained_calls - before == calls
+        for k in range(calls):
+            ref = army.mix(xs[k])
+            bad = army.differing(dy[k].cpu().numpy(), ref)
+            assert not bad, f"call {k}: {len(bad)} instances differ, the first {bad[:6]}"
+        for s in army.shadows[::97]:
+            d = s.compare_state()
+            assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
