@@ -884,8 +884,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // ST build: 8 hand-over rows behind the table; the modulation smoother's row (MD) lives only inside next_mod_delays and shares the first
     auto strow = [&](int k) -> float* { return utf + ut::SIZE + k * kRow; };
     float* modrow = utf + ut::SIZE;
-    int mod_tiles = 0;
-    int mod_base = (v_modidx >= 0 && v_modidx < v_modrange) ? v_modidx : -1; // the modulator's index at the start of the next tile to prepare (-1: not kept)
+    int mod_pos = v_modidx; // the modulator's index at the first sample of the next tile to prepare (the state keeps it in [0, range))
     auto next_mod_delays = [&](int samples_or_64) -> int { // RG: what the tile holds (a ragged call's last tile holds fewer than 64)
         const int samples = RG ? samples_or_64 : 64;
         if (lane == 0) {
@@ -903,15 +902,15 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // (the index of this lane's sample modulo the range: carried from tile to tile by additions where the range is at least a tile
         // long -- the division by a run-time divisor is some thirty-five vector instructions)
         int index;
-        if (v_modrange >= 64 && mod_base >= 0) {
-            index = mod_base + lane;
+        if (!RG && v_modrange >= 64) { // (the ragged builds: the branch costs the stereo one two registers it does not have)
+            index = mod_pos + lane;
             if (index >= v_modrange) index -= v_modrange;
-            mod_base += 64;
-            if (mod_base >= v_modrange) mod_base -= v_modrange;
+            mod_pos += 64;
+            if (mod_pos >= v_modrange) mod_pos -= v_modrange;
         } else {
-            index = (v_modidx + (mod_tiles << 6) + lane) % v_modrange;
+            index = (mod_pos + lane) % v_modrange;
+            mod_pos += 64;
         }
-        mod_tiles += 1;
         const float sinus = glibc_sinf(6.28318530717958647692F * index / v_modrange);
         return lround_away(fv * sinus);
     };
