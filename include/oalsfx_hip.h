@@ -104,6 +104,36 @@ void oalsfx_pinned_free(void* p);
  * oalsfx_batch_mix_device(..., NULL) is in the order of that stream (no overlap of consecutive calls). */
 void* oalsfx_batch_stream(oalsfx_batch* b);
 
+/* ---- one instance range over several GPUs (BASELINE configs[4]: 262 144 EAX reverbs over the eight GPUs of a node).  The reference's
+ * instances share nothing (src/oalsfxpp.cpp:2984-3037), so the split is a contiguous range per device -- sizes differ by at most one --,
+ * one batch, one stream set and one host thread per device, no collective and no peer traffic.  device_ids lists the HIP ordinals (an
+ * ordinal may appear more than once: two shards on one GPU, which is how the split is rehearsed on a one-GPU box).  Setters take ranges
+ * of the global instance numbering; the buffers of oalsfx_group_mix hold the whole range, [n_total][frames][channels], in host memory,
+ * and every device's thread copies its part in, runs its kernels and copies out (Api::mix, src/oalsfxpp.cpp:3785-3829, for every
+ * instance); oalsfx_group_mix_device takes one device-resident source and target buffer per shard and only queues (consecutive calls
+ * overlap on every device as for a batch alone), oalsfx_group_synchronize waits for all.  A failed call's message (oalsfx_group_error)
+ * names the device; oalsfx_group_last_error is for a failed create.  Not thread-safe, like a batch. */
+typedef struct oalsfx_group oalsfx_group;
+oalsfx_group* oalsfx_group_create(int n_total, const int* device_ids, int n_devices, int channel_format, int sampling_rate, int effect_count);
+void oalsfx_group_destroy(oalsfx_group* g);
+const char* oalsfx_group_error(const oalsfx_group* g);
+const char* oalsfx_group_last_error(void);
+int oalsfx_group_instances(const oalsfx_group* g);
+int oalsfx_group_channels(const oalsfx_group* g);
+int oalsfx_group_devices(const oalsfx_group* g);
+/* Shard k: its device ordinal, first global instance and instance count; and its batch, for what the group does not forward (read-backs,
+ * oalsfx_batch_plan, the pipelined host path). */
+int oalsfx_group_shard(const oalsfx_group* g, int k, int* device_id, int* first, int* count);
+oalsfx_batch* oalsfx_group_batch(oalsfx_group* g, int k);
+int oalsfx_group_set_effect(oalsfx_group* g, int first, int count, int slot, const oalsfx_effect* effects, int stride_bytes);
+int oalsfx_group_set_effect_type(oalsfx_group* g, int first, int count, int slot, int effect_type);
+int oalsfx_group_set_effect_props(oalsfx_group* g, int first, int count, int slot, const void* props, int stride_bytes);
+int oalsfx_group_set_send_props(oalsfx_group* g, int first, int count, int slot, const oalsfx_send_props* props);
+int oalsfx_group_apply_changes(oalsfx_group* g, int first, int count);
+int oalsfx_group_mix(oalsfx_group* g, int frames, const float* src_host, float* dst_host);
+int oalsfx_group_mix_device(oalsfx_group* g, int frames, const float* const* src_per_device, float* const* dst_per_device);
+int oalsfx_group_synchronize(oalsfx_group* g);
+
 /* ---- device memory the library keeps between batches.  Batches whose calls can overlap on the device keep their delay lines, effect
  * state and hot records in uncached device memory, which the library takes from the runtime in 2 MiB granules and keeps for the next
  * batch that asks for a block of that size -- by default for the life of the process: on this runtime, uncached blocks given back with

@@ -272,19 +272,13 @@ struct DedicatedW {
 
 // chorus / flanger (reference src/oalsfxpp.cpp:4113-4276, 5384-5547): buf[o] = in; t = buf[o - d] * feedback; buf[o] += t; out = t
 struct ModDelayW {
+    // (The LFO's phase, `offset % lfo_range`, is an integer division by a run-time divisor per lane, twice per tile.  Round 4 carried
+    // the remainder from tile to tile by additions instead -- one division per call -- and measured it: 4096 choruses 12.6 -> 13.7 us
+    // per buffer, flangers 12.6 -> 13.7, config 3 93.2 -> 96.8, with the branch on a wave-uniform flag or not
+    // (profiles/r04c_instruction_diet/lfo_phase_by_additions.txt).  The tile is a chain of latencies behind the dependent ring load;
+    // the division was never on it.  Taken out again.)
     int offset;
-    // The LFO's phase is `offset % lfo_range` (and the right side's `(offset + lfo_disp) % lfo_range`): an integer division by a run-time
-    // divisor, some thirty-five vector instructions each, per lane and twice per tile -- where the offset only ever grows by the tile's
-    // length.  So the remainder is taken once per call and carried from tile to tile by additions (phase0 >= 0); a negative offset
-    // (after 2^31 samples: the reference's int wraps, and C++'s % then yields negative phases) or a range under a tile's length keeps
-    // the division per sample (phase0 == -1).  Round 3's verdict: config 3 and config 4 are bound by instruction issue.
-    int phase0;
-    __device__ void init(const Inst& I)
-    {
-        offset = I.ss->u.moddelay.offset;
-        const int range = I.sp->u.moddelay.lfo_range;
-        phase0 = (offset >= 0 && offset < (1 << 30) && range >= 64) ? offset % range : -1;
-    }
+    __device__ void init(const Inst& I) { offset = I.ss->u.moddelay.offset; }
     template <class P> __device__ static int lfo_delay(const P& p, int phase)
     {
         if (p.waveform == 1) return static_cast<int>((1.0F - fabsf(2.0F - (p.lfo_scale * phase))) * p.depth) + p.delay;
@@ -308,18 +302,7 @@ struct ModDelayW {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            int phase;
-            if (phase0 >= 0) {
-                // (phase0 < range, lane < 64 <= range, 0 <= lfo_disp <= range: one conditional subtraction each)
-                phase = phase0 + lane;
-                if (phase >= p.lfo_range) phase -= p.lfo_range;
-                if (k) {
-                    phase += p.lfo_disp;
-                    if (phase >= p.lfo_range) phase -= p.lfo_range;
-                }
-            } else {
-                phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
-            }
+            const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
             d[k] = lfo_delay(p, phase);
             inside[k] = d[k] > 0 && lane - d[k] >= 0; // written by an earlier lane of this tile
             v[k] = in;
@@ -386,11 +369,6 @@ struct ModDelayW {
         for (int k = 0; k < 2; ++k) pan<CH>(out, I.channels, p.gains[k], t[k]);
         // `out += t * g` in the reference; the product commutes
         offset += L;
-        if (phase0 >= 0) {
-            phase0 += L;
-            if (phase0 >= p.lfo_range) phase0 -= p.lfo_range;
-            if (offset >= (1 << 30)) phase0 = -1;
-        }
         wave_sync();
     }
     __device__ void finish(const Inst& I)

@@ -53,6 +53,23 @@ SIGNATURES = {
     "oalsfx_batch_placement": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
     "oalsfx_batch_chained_calls": (C.c_longlong, [C.c_void_p]),
+    "oalsfx_group_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "oalsfx_group_destroy": (None, [C.c_void_p]),
+    "oalsfx_group_error": (C.c_char_p, [C.c_void_p]),
+    "oalsfx_group_last_error": (C.c_char_p, []),
+    "oalsfx_group_instances": (C.c_int, [C.c_void_p]),
+    "oalsfx_group_channels": (C.c_int, [C.c_void_p]),
+    "oalsfx_group_devices": (C.c_int, [C.c_void_p]),
+    "oalsfx_group_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "oalsfx_group_batch": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "oalsfx_group_set_effect": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "oalsfx_group_set_effect_type": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "oalsfx_group_set_effect_props": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "oalsfx_group_set_send_props": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(desc.SendProps)]),
+    "oalsfx_group_apply_changes": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "oalsfx_group_mix": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "oalsfx_group_mix_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "oalsfx_group_synchronize": (C.c_int, [C.c_void_p]),
     "oalsfx_trim_pools": (C.c_ulonglong, []),
     "oalsfx_pools_waiting_bytes": (C.c_ulonglong, []),
     "oalsfx_debug_chain_same_cu": (C.c_longlong, [C.c_void_p]),

@@ -19,7 +19,7 @@ HEADERS = [os.path.join(ROOT, "include", h) for h in ("oalsfx_hip.h", "oalsfx_hi
 def declared_functions():
     text = "".join(open(h).read() for h in HEADERS)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned|trim|pools)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(oalsfx_(?:batch|host|last|debug|device|pinned|trim|pools|group)_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
