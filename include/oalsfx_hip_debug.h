@@ -64,6 +64,11 @@ int oalsfx_debug_probe_pointer(void* slabs, int instances, int slab_floats, int 
  * i * pos_skew samples inside its streams).  Returns the average launch time of `repeats` launches. */
 int oalsfx_debug_stream_pattern(int device_id, int instances, int dwords_per_lane, int repeats, int slab_floats, int pos_skew, double* avg_us);
 
+/* The pipelined host-pointer path (oalsfx_batch_mix_async): which form the batch settled on -- 3: copy in, kernels and copy out of
+ * successive calls on three streams; 1: all three on the batch's one stream, in order; 0: still probing -- and what its probe saw per call
+ * in either form (microseconds; 0 where no probe ran: the form was known for the device, or fixed by OALSFX_HOST_PIPELINE). */
+int oalsfx_debug_host_pipeline(oalsfx_batch* b, int* form, double* probe_us_three_streams, double* probe_us_one_stream);
+
 /* Chained launches: the gate in front of a launch is set by the host's count of the workgroups started so far, which every
  * workgroup of a chained launch adds itself to on the device.  Reads both (waits for the batch): the two must agree after any run. */
 int oalsfx_debug_chain_started(oalsfx_batch* b, unsigned* host_total, unsigned* device_total);

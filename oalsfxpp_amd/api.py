@@ -203,6 +203,12 @@ class Batch:
         """mix_device calls (own stream) that overlapped with their neighbours on the device so far."""
         return self._lib.oalsfx_batch_chained_calls(self._h)
 
+    def host_pipeline(self):
+        """(form, probe us per call on three streams, probe us per call on one stream) of mix_async; form 0: still probing."""
+        f, a, c = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._lib.oalsfx_debug_host_pipeline(self._h, C.byref(f), C.byref(a), C.byref(c))
+        return f.value, a.value, c.value
+
     def chain_started(self):
         """(host count, device count) of the workgroups of chained launches started so far: the two must agree.  Waits."""
         h, d = C.c_uint(0), C.c_uint(0)
@@ -300,3 +306,74 @@ def trim_pools():
 
 def pools_waiting_bytes():
     return lib.load().oalsfx_pools_waiting_bytes()
+
+
+class Group:
+    """One instance range over several devices (oalsfx_group_*): a batch and a host thread per device, contiguous shards."""
+
+    def __init__(self, n_total, device_ids, channel_format=desc.FMT_STEREO, sampling_rate=48000, effect_count=1):
+        self._lib = lib.load()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = self._lib.oalsfx_group_create(n_total, ids, len(device_ids), channel_format, sampling_rate, effect_count)
+        if not h:
+            raise BatchError(self._lib.oalsfx_group_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n = n_total
+        self.channels = self._lib.oalsfx_group_channels(self._h)
+        self.shards = []
+        for k in range(self._lib.oalsfx_group_devices(self._h)):
+            d, f, c = C.c_int(), C.c_int(), C.c_int()
+            self._lib.oalsfx_group_shard(self._h, k, C.byref(d), C.byref(f), C.byref(c))
+            self.shards.append((d.value, f.value, c.value))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.oalsfx_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, ok):
+        if not ok:
+            raise BatchError(self._lib.oalsfx_group_error(self._h).decode())
+
+    def set_effect_type(self, slot, effect_type, first=0, count=None):
+        self._check(self._lib.oalsfx_group_set_effect_type(self._h, first, self.n - first if count is None else count, slot, effect_type))
+
+    def set_effect(self, slot, effects, first=0):
+        """effects: one desc.Effect for the whole range from `first` on, or a list of them (one per instance from `first` on)."""
+        if isinstance(effects, desc.Effect):
+            self._check(self._lib.oalsfx_group_set_effect(self._h, first, self.n - first, slot, C.byref(effects), 0))
+        else:
+            arr = (desc.Effect * len(effects))(*effects)
+            self._check(self._lib.oalsfx_group_set_effect(self._h, first, len(effects), slot, arr, C.sizeof(desc.Effect)))
+
+    def set_send_props(self, slot, gain, gain_hf, gain_lf, first=0, count=None):
+        sp = desc.SendProps(gain, gain_hf, gain_lf)
+        self._check(self._lib.oalsfx_group_set_send_props(self._h, first, self.n - first if count is None else count, slot, C.byref(sp)))
+
+    def apply_changes(self, first=0, count=None):
+        self._check(self._lib.oalsfx_group_apply_changes(self._h, first, self.n - first if count is None else count))
+
+    def mix(self, src):
+        """src: float32 [n_total][frames][channels] in host memory; returns the output array."""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        frames = src.shape[1]
+        dst = np.empty_like(src)
+        self._check(self._lib.oalsfx_group_mix(self._h, frames, src.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p)))
+        return dst
+
+    def mix_device(self, frames, src_ptrs, dst_ptrs):
+        """One device pointer per shard each (that shard's [count][frames][channels]); queues and returns."""
+        s = (C.c_void_p * len(src_ptrs))(*src_ptrs)
+        d = (C.c_void_p * len(dst_ptrs))(*dst_ptrs)
+        self._check(self._lib.oalsfx_group_mix_device(self._h, frames, s, d))
+
+    def synchronize(self):
+        self._check(self._lib.oalsfx_group_synchronize(self._h))

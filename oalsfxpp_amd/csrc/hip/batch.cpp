@@ -165,6 +165,19 @@ struct oalsfx_batch {
     size_t pipe_capacity = 0;
     long long pipe_turn = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    // How successive calls of oalsfx_batch_mix_async share the link: form 3: the copy in of call k + 1, the kernels of call k and the copy
+    // out of call k - 1 on three streams, both directions busy at once; form 1: copy in, kernels and copy out of a call on the batch's one
+    // stream, in order -- the synchronous call's sequence without its wait.  Some hosts' copy engines run the two directions far below the
+    // link's rate when both are busy (round 3's driver box: 0.48 ms per step on three streams against 0.38 synchronous), on others three
+    // streams are fastest (0.20 - 0.24 ms): decided per device by the first calls of the first batch that pipelines -- sixteen calls to
+    // set everything up, sixteen on one stream, sixteen on three, the host's clock over the last twelve of either (the pipeline paces the caller: a call waits for
+    // the one that used its staging slot three calls ago) -- and remembered; the single stream has to win by a tenth.
+    // OALSFX_HOST_PIPELINE=1|3 fixes the form.  (Also built and measured, round 4: both copies on one stream in turn, the copy out of a
+    // call queued behind the next call's copy in, the kernels beside them -- 0.41 ms where the synchronous call takes 0.37 and three
+    // streams 0.24: a copy engine that changes direction every copy is slower than either.)
+    int pipe_mode = 0;                      // 0: probing
+    std::chrono::steady_clock::time_point pipe_probe_t0;
+    double pipe_probe_us[2] = {0.0, 0.0};   // per call: what the probe saw on three streams / on one
 
     unsigned long long* d_timeline = nullptr;    // measurement only (OALSFX_DEBUG_TIMELINE=<file>)
     // Parameter uploads: the changed records are packed into pinned memory and put in place by one kernel (k_upload); four buffers
@@ -1998,6 +2011,40 @@ int oalsfx_batch_mix_timed(oalsfx_batch* b, int frames, const float* src_host, f
     return mix_host(b, frames, src_host, dst_host, legs_us);
 }
 
+namespace {
+
+std::mutex g_pipe_mutex;
+std::map<int, int> g_pipe_mode; // device -> form, once a batch has probed it
+
+// Which form this call of oalsfx_batch_mix_async takes (oalsfx_batch::pipe_mode); while probing, also the probe's bookkeeping.
+int pipe_form(oalsfx_batch* b)
+{
+    if (b->pipe_mode) return b->pipe_mode;
+    if (const char* e = std::getenv("OALSFX_HOST_PIPELINE")) {
+        const int m = std::atoi(e);
+        if (m == 1 || m == 3) return b->pipe_mode = m;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_pipe_mutex);
+        auto it = g_pipe_mode.find(b->device);
+        if (it != g_pipe_mode.end()) return b->pipe_mode = it->second;
+    }
+    // probing: calls 0 .. 15 on three streams (streams, events and staging buffers come into being, the copy engines see the caller's
+    // buffers for the first time: not timed -- these calls took 1.2 ms each where the steady state takes 0.24), 16 .. 31 on one stream,
+    // 32 .. 47 on three again; the clock runs over the last twelve of the second and third sixteen
+    const long long k = b->pipe_turn;
+    const auto now = std::chrono::steady_clock::now();
+    if ((k & 15) == 4) b->pipe_probe_t0 = now;
+    if (k == 32 || k == 48) b->pipe_probe_us[k == 48 ? 0 : 1] = std::chrono::duration<double, std::micro>(now - b->pipe_probe_t0).count() / 12.0;
+    if (k < 48) return (k >= 16 && k < 32) ? 1 : 3;
+    b->pipe_mode = b->pipe_probe_us[1] < b->pipe_probe_us[0] * 0.9 ? 1 : 3;
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    g_pipe_mode[b->device] = b->pipe_mode;
+    return b->pipe_mode;
+}
+
+} // namespace
+
 int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, float* dst_host)
 {
     if (frames == 0) return 1;
@@ -2017,7 +2064,7 @@ int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, f
     }
     if (floats > b->pipe_capacity) {
         // a larger call than any before: let the pipeline drain, then grow every slot
-        if (!b->hip_ok(hipStreamSynchronize(b->d2h_stream), "hipStreamSynchronize")) return 0;
+        if (!b->hip_ok(hipStreamSynchronize(b->d2h_stream), "hipStreamSynchronize") || !b->hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize")) return 0;
         for (auto& ps : b->pipe) {
             hipFree(ps.d_src); hipFree(ps.d_dst);
             ps.d_src = ps.d_dst = nullptr;
@@ -2030,10 +2077,18 @@ int oalsfx_batch_mix_async(oalsfx_batch* b, int frames, const float* src_host, f
         }
         b->pipe_capacity = floats;
     }
+    const int form = pipe_form(b);
     oalsfx_batch::PipeSlot& ps = b->pipe[b->pipe_turn++ % oalsfx_batch::kPipeDepth];
     // the call that used this staging slot kPipeDepth calls ago must be through: its output copy is the last thing it does
     if (ps.busy && !b->hip_ok(hipEventSynchronize(ps.copied_out), "hipEventSynchronize")) return 0;
     ps.busy = true;
+    if (form == 1) {
+        // one stream: the synchronous call's sequence, without its wait
+        if (!b->hip_ok(hipMemcpyAsync(ps.d_src, src_host, floats * sizeof(float), hipMemcpyHostToDevice, b->stream), "hipMemcpyAsync(src)")) return 0;
+        if (!mix_device(b, frames, ps.d_src, ps.d_dst, b->stream)) return 0;
+        if (!b->hip_ok(hipMemcpyAsync(dst_host, ps.d_dst, floats * sizeof(float), hipMemcpyDeviceToHost, b->stream), "hipMemcpyAsync(dst)")) return 0;
+        return b->hip_ok(hipEventRecord(ps.copied_out, b->stream), "hipEventRecord") ? 1 : 0;
+    }
     // The copies go through the runtime's copy engines.  (Experiment, OALSFX_DEBUG_FLAGS 0x800000: as kernels reading / writing the
     // page-locked buffers directly.  Measured slower, 0.32 against 0.20 ms per step: the reverb grid holds every CU, and the copy
     // kernels' workgroups wait for its slots.)
@@ -2241,6 +2296,14 @@ long long oalsfx_debug_chain_same_cu(oalsfx_batch* b)
     if (hipSetDevice(b->device) != hipSuccess || !chain_join(b) || hipStreamSynchronize(b->stream) != hipSuccess) return -1;
     if (hipMemcpy(&v, b->d_turn + static_cast<size_t>(b->n) * b->slots + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return v;
+}
+
+int oalsfx_debug_host_pipeline(oalsfx_batch* b, int* form, double* probe_us_three_streams, double* probe_us_one_stream)
+{
+    if (form) *form = b->pipe_mode;
+    if (probe_us_three_streams) *probe_us_three_streams = b->pipe_probe_us[0];
+    if (probe_us_one_stream) *probe_us_one_stream = b->pipe_probe_us[1];
+    return 1;
 }
 
 unsigned long long oalsfx_trim_pools(void)

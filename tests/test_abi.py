@@ -83,3 +83,15 @@ def test_the_pool_entry_points_answer_without_a_gpu():
     so = lib.load()
     assert so.oalsfx_pools_waiting_bytes() == 0
     assert so.oalsfx_trim_pools() == 0
+
+
+def test_group_create_fails_loudly_without_a_gpu_and_names_the_device():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    so = lib.load()
+    ids = (C.c_int * 2)(0, 1)
+    assert not so.oalsfx_group_create(8, ids, 2, desc.FMT_STEREO, 48000, 1)
+    assert so.oalsfx_group_last_error() == b"device 0: No HIP device available: the effect process path has no CPU fallback."
+    assert not so.oalsfx_group_create(1, ids, 2, desc.FMT_STEREO, 48000, 1)
+    assert b"fewer instances than devices" in so.oalsfx_group_last_error()

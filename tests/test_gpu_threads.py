@@ -74,3 +74,46 @@ def test_api_objects_on_four_threads_match_the_serial_run(tmp_path):
                     "-L", libdir, "-loalsfx_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr + r.stdout
+
+
+def test_a_group_of_two_shards_on_one_gpu_matches_one_batch(tmp_path):
+    """tests/cpp/group_two_shards.cpp: the multi-GPU split of the C ABI (oalsfx_group_*: a contiguous instance range, a batch and a host
+    thread per device, no collective), rehearsed with both shards on device 0 -- every buffer bit-identical to one batch of all the
+    instances, setters that straddle the shard boundary, a change while streaming."""
+    exe = str(tmp_path / "group_two_shards")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "group_two_shards.cpp"),
+                    "-L", libdir, "-loalsfx_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    for n in ("37", "2048"):
+        r = subprocess.run([exe, n], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr + r.stdout
+
+
+def test_group_device_buffers_and_three_shards():
+    """The device-buffer entry point of a group (queued shard after shard, consecutive calls chained per shard) against single batches of
+    the same instance ranges; three shards of unequal size on device 0."""
+    import torch
+    from oalsfxpp_amd.api import Group
+    n, frames, calls = 70, 256, 12
+    with Group(n, [0, 0, 0], desc.FMT_STEREO, 48000, 1) as g:
+        assert [c for _, _, c in g.shards] == [24, 23, 23] and [f for _, f, _ in g.shards] == [0, 24, 47]
+        effects = [preset_effect((3 * i) % 113) for i in range(n)]
+        g.set_effect(0, effects)
+        g.apply_changes()
+        xs = [np.stack([orc.synth(900 + i, k, frames * 2).reshape(frames, 2) for i in range(n)]) for k in range(calls)]
+        outs = []
+        for _, f, c in g.shards:
+            dx = [torch.from_numpy(x[f:f + c].copy()).cuda() for x in xs]
+            outs.append((dx, [torch.empty_like(d) for d in dx]))
+        torch.cuda.synchronize()
+        for k in range(calls):
+            g.mix_device(frames, [o[0][k].data_ptr() for o in outs], [o[1][k].data_ptr() for o in outs])
+        g.synchronize()
+        with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+            b.set_effect(0, effects)
+            b.apply_changes()
+            for k in range(calls):
+                want = b.mix(xs[k])
+                got = np.concatenate([o[1][k].cpu().numpy() for o in outs])
+                ok, nbad = same_bits(got, want)
+                assert ok, f"call {k}: {nbad} samples differ"
