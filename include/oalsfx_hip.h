@@ -75,6 +75,9 @@ int oalsfx_batch_apply_changes(oalsfx_batch* b, int first, int count);
  * src and dst hold n_instances * frames * channels floats.  frames may be any positive count;
  * more than 2048 are processed in 2048-frame chunks like the reference.  frames == 0 succeeds. */
 int oalsfx_batch_mix(oalsfx_batch* b, int frames, const float* src_host, float* dst_host);
+/* The same for a caller whose instances each have a source and a target buffer of their own (n_instances pointers each, every buffer
+ * frames * channels floats): what a program that held one oalsfxpp::Api object per voice has.  Gathered, mixed as one call, scattered. */
+int oalsfx_batch_mix_gather(oalsfx_batch* b, int frames, const float* const* src_per_instance, float* const* dst_per_instance);
 /* Same with buffers already resident in device memory; launches on `hip_stream` (a hipStream_t, or
  * NULL for the batch's own stream) and returns without synchronising.
  * With hip_stream NULL the call is complete when oalsfx_batch_synchronize (or any other call on the batch that waits or reads back)

@@ -18,7 +18,7 @@ _TAG = os.environ.get("OALSFX_BUILD_TAG", "")
 OUT = os.path.join(ROOT, "ab", f"liboalsfx_hip_{_TAG}.so") if _TAG else os.path.join(CSRC, "liboalsfx_hip.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj_" + _TAG if _TAG else "obj")
 
-HOST_SOURCES = ["host/props.cpp", "host/panning.cpp", "host/update.cpp", "host/hostabi.cpp", "host/api.cpp", "host/group.cpp"]
+HOST_SOURCES = ["host/props.cpp", "host/panning.cpp", "host/update.cpp", "host/hostabi.cpp", "host/api.cpp", "host/api_array.cpp", "host/group.cpp"]
 HIP_SOURCES = ["hip/batch.cpp", "hip/reverb.hip", "hip/support_kernels.hip", "hip/wave_effects.hip"]
 
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-unused-parameter",

@@ -52,6 +52,7 @@ SIGNATURES = {
     "oalsfx_batch_plan": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "oalsfx_batch_placement": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oalsfx_batch_last_reverb_kernel": (C.c_char_p, [C.c_void_p]),
+    "oalsfx_batch_mix_gather": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "oalsfx_batch_chained_calls": (C.c_longlong, [C.c_void_p]),
     "oalsfx_group_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
     "oalsfx_group_destroy": (None, [C.c_void_p]),

@@ -117,3 +117,14 @@ def test_group_device_buffers_and_three_shards():
                 got = np.concatenate([o[1][k].cpu().numpy() for o in outs])
                 ok, nbad = same_bits(got, want)
                 assert ok, f"call {k}: {nbad} samples differ"
+
+
+def test_api_array_matches_separate_api_objects(tmp_path):
+    """tests/cpp/api_array.cpp: oalsfxpp::ApiArray (include/oalsfxpp_array.h) -- the reference's Api surface for many chains at once, each
+    with buffers of its own (oalsfx_batch_mix_gather) -- against the same forty chains as forty oalsfxpp::Api objects: bit-identical."""
+    exe = str(tmp_path / "api_array")
+    libdir = os.path.dirname(lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "api_array.cpp"),
+                    "-L", libdir, "-loalsfx_hip", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr + r.stdout
