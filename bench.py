@@ -484,6 +484,14 @@ def main():
         # VALU issue slots the step uses, from the committed counter pass (wave-level VALU instructions per step) and this run's step time.
         with open(issue_file) as f:
             vi = json.load(f).get(workload)
+        # (the count belongs to the kernels it was taken from: where the file's steady-state reverb kernel is not the one this run
+        # launched -- another build of the library, an experiment flag --, the step keeps its HBM roofline and says why.  ADVICE, round 3)
+        counted = [k for k in (vi or {}).get("kernels", {}) if k.startswith("k_reverb_steady")]
+        launched = batch.last_reverb_kernel
+        if vi and counted and launched.startswith("k_reverb_steady") and launched not in counted:
+            roofline["valu_issue_note"] = (f"profiles/valu_issue.json counts {counted[0]}, this run launched {launched}: no VALU-issue figure "
+                                           "(refresh with scripts/pmc_configs.sh)")
+            vi = None
         if vi:
             insts = vi["valu_wave_instructions_per_step"]
             peak = VALU_SIMDS * VALU_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTRUCTION   # G wave-instructions per second

@@ -1047,7 +1047,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // change go to the general kernel for 128 frames, as before round 3, 0x1000000 the believed kind of k_reverb_steady_kinds without the
 // general path inside (experiment: what the fallback's scratch frame costs the grid), 0x200 no send filters inside the steady-state
 // builds (the pre-pass kernel for every filtered instance, as before round 3), 0x400 no chained launches: consecutive calls in plain
-// stream order (bench.py --no-chain), 0x2000 no proven ragged builds (calls that end in a partial tile on the believing build, in stream
+// stream order (bench.py --no-chain), 0x8000 chained launches for short calls of small batches too (tests of the hand-over with few
+// workgroups; measured slower: chain_eligible), 0x2000 no proven ragged builds (calls that end in a partial tile on the believing build, in stream
 // order: as before round 4), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
 // of tests/test_gpu_chained.py: it must fail).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
@@ -1400,6 +1401,11 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
     if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK) return false;
+    // Short calls of a batch that leaves workgroup slots free gain nothing from the overlap and can lose by it: the next launch's
+    // workgroups are on the chip at once, waiting, beside the ones they wait for (2048 instances x 64 frames: 16.7 us per step chained,
+    // 13.4 in stream order; x 128: 22.3 against 19.5; from 256 frames on, and with every slot taken, chained is level or ahead:
+    // profiles/r04e_round4_end/chained/instances_and_call_sizes.txt).
+    if ((b->n + 3) / 4 < 1024 && frames < 256 && !(debug_flags() & 0x8000)) return false;
     const int steady = b->fast_count[0] + b->slow_count[0];
     if (steady != b->n || b->general_count[0] != 0) return false;
     if ((frames & 63) != 0) {

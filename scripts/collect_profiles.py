@@ -1,9 +1,10 @@
 """Copies what `scripts/round_end.sh <name>` left under gpurun_out/<name>/ into profiles/<name>/ (the summaries that are kept; traces and
-raw counter files stay behind) and the chained-launch evidence into profiles/r03k_chained_launches/.
+raw counter files stay behind) and the chained-launch evidence into profiles/<name>/chained/.
     python3 scripts/collect_profiles.py r03n_round3_end"""
 import glob, os, shutil, sys
 name = sys.argv[1]
-S, D, K = f"gpurun_out/{name}", f"profiles/{name}", "profiles/r03k_chained_launches"
+S, D = f"gpurun_out/{name}", f"profiles/{name}"
+K = D + "/chained"   # (round 3 kept its chained-launch evidence in profiles/r03k_chained_launches)
 os.makedirs(D, exist_ok=True); os.makedirs(K, exist_ok=True)
 def lastline(f):
     return [l for l in open(f) if l.startswith("{")][-1]

@@ -21,6 +21,20 @@ pytestmark = [pytest.mark.gpu,
 
 E = make_effect
 
+# The product leaves short calls of small batches in stream order (chain_eligible, batch.cpp: measured slower chained); these tests are
+# about the hand-over itself, with few workgroups above all, so they ask for it everywhere (OALSFX_DEBUG_FLAGS 0x8000).
+CHAIN_ALWAYS = 0x8000
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _chain_short_calls_of_small_batches_too():
+    import os
+    so = lib.load()
+    base = int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0)
+    so.oalsfx_debug_set_flags(base | CHAIN_ALWAYS)
+    yield
+    so.oalsfx_debug_set_flags(base)
+
 
 def run_device_calls(b, script, shadows, seed, replicas=True):
     """`script`: frame counts, or callables run between calls.  Device-resident buffers, one output buffer per call, every input
@@ -582,7 +596,7 @@ def test_ragged_calls_inside_a_run_at_full_size():
 def _with_debug_flags(flags, body):
     import os
     so = lib.load()
-    base = int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0)
+    base = int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0) | CHAIN_ALWAYS
     so.oalsfx_debug_set_flags(base | flags)
     try:
         return body()
@@ -677,3 +691,31 @@ def test_every_instance_through_consecutive_chained_calls_at_full_size(workload)
         for s in army.shadows[::97]:
             d = s.compare_state()
             assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
+
+
+def test_short_calls_of_small_batches_stay_in_stream_order():
+    """What the product does without the test switch: a batch that leaves workgroup slots free chains its calls from 256 frames on
+    (2048 instances x 64 frames measured 16.7 us per step chained against 13.4 in stream order); with every slot taken, always."""
+    import os
+    import torch
+    so = lib.load()
+    base = int(os.environ.get("OALSFX_DEBUG_FLAGS", "0"), 0)
+    so.oalsfx_debug_set_flags(base)
+    try:
+        for n, expect in ((72, {64: 0, 128: 0, 256: 8, 512: 8}), (4096, {64: 8, 256: 8})):
+            with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+                b.set_effect_type(0, desc.EAX_REVERB)
+                b.apply_changes()
+                x = torch.zeros(n * 512 * 2, device="cuda")
+                y = torch.empty_like(x)
+                for _ in range(4):
+                    b.mix_device(256, x.data_ptr(), y.data_ptr())
+                    b.synchronize()
+                for frames, chained in expect.items():
+                    before = b.chained_calls
+                    for _ in range(8):
+                        b.mix_device(frames, x.data_ptr(), y.data_ptr())
+                    b.synchronize()
+                    assert b.chained_calls - before == chained, (n, frames, b.chained_calls - before)
+    finally:
+        so.oalsfx_debug_set_flags(base | CHAIN_ALWAYS)
