@@ -144,6 +144,9 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 #ifndef OALSFX_AW
 #define OALSFX_AW 1
 #endif
+#ifndef OALSFX_EARLY_HANDBACK
+#define OALSFX_EARLY_HANDBACK 1 // FP builds write state and hot record in front of the last tile's S5 instead of behind the loop (0: as before, same-box A/B)
+#endif
 #ifndef OALSFX_CR_FEED
 #define OALSFX_CR_FEED 0 // 1: the plain FP builds for write positions on the grid hold the late feed's stores back too (CR == 1; measured: no gain)
 #endif
@@ -1064,6 +1067,85 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     unsigned long long ramp_mask = 0ULL;
     // ... and where the stepped gains of a tile go: rows of the late half that are idle in S5, and hand-over rows
     auto grow = [&](int q) -> float* { return q < 12 ? rowL(q >> 2, q & 3) + 4 : utf + ut::SIZE + (2 + q - 12) * kRow + 4; };
+    // What the call leaves for the next one: the canonical state and, from an FP build, the hot record.  In an FP build this runs in the
+    // call's last iteration, in front of S5 (OALSFX_EARLY_HANDBACK): every filter history is final once that iteration's chain phases are
+    // through -- S5 only writes delay lines and output frames --, so the stores travel while S5 computes instead of standing between the
+    // last ring store and the word that hands the instance on.
+    constexpr bool EH = OALSFX_EARLY_HANDBACK && FP && !RG && !SF && !ST; // (the ragged, send-filter and short-tap builds have no registers for it: they spill)
+    auto hand_back = [&]() {
+        if (go) {
+            if (lane < 4) {
+                const float* ch = chain_all[wib][lane];
+                S.lp[lane].x[0] = ch[coop::LPX0]; S.lp[lane].x[1] = ch[coop::LPX1];
+                S.lp[lane].y[0] = ch[coop::LPY0]; S.lp[lane].y[1] = ch[coop::LPY1];
+                if (eax) {
+                    S.hp[lane].x[0] = ch[coop::LPY0]; S.hp[lane].x[1] = ch[coop::LPY1];
+                    S.hp[lane].y[0] = ch[coop::HPY0]; S.hp[lane].y[1] = ch[coop::HPY1];
+                }
+                S.t60[lane][0][0] = ch[coop::T60X]; S.t60[lane][0][1] = ch[coop::T60O1];
+                S.t60[lane][1][0] = ch[coop::T60O1]; S.t60[lane][1][1] = ch[coop::T60O2];
+            }
+            if (lane == 0) {
+                S.mod_index = static_cast<int>((static_cast<long long>(v_modidx) + frames) % v_modrange);
+                S.offset = offset + frames;
+                if (MD && mod_on) S.mod_filter = mod_f;
+            }
+            if (XF && xf_active) {
+                // the transition's own state: gains where the ramps left them, the fade count, the taps once they are faded in, the change
+                // marked as seen; and whether the instance ends the call settled and at rest
+                if (q_valid) {
+                    if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
+                    else S.early_cur_gain[q_line][q_chan] = g_cur;
+                }
+                const bool fade_over = fc >= OALSFX_RV_FADE_SAMPLES;
+                if (fc0 < OALSFX_RV_FADE_SAMPLES && fade_over && lane < 24) (&S.cur_early_tap[0])[lane] = static_cast<int32_t>(utu[kTapN + lane] >> 2);
+                if (lane == 0) {
+                    S.fade_count = fc;
+                    S.mod_range = v_modrange;
+                    SS.seen_seq = SP.update_seq;
+                }
+                if (ctx.exact) {
+                    const unsigned level = gains_rest_level(q_valid, g_cur, g_tgt);
+                    if (lane == 0) ctx.exact[sidx] = fade_over ? level : 0u;
+                }
+            }
+            if (SF && sf) {
+                // the send filters' histories as the recurrence lanes left them (the second shelf's input history is the first one's output)
+                if (lane < kSfRows) {
+                    const int sd = lane / CH, c = lane % CH, at = sd ? 1 + slot : 0;
+                    if (reinterpret_cast<const int*>(sfmisc + sfm::TAB + 12 * sd)[10] & 4) {
+                        const float* h = sfmisc + sfm::HIST + 6 * lane;
+                        oalsfx_source_state& SGs = ctx.source_state[inst];
+                        oalsfx_hist_t lp, hp;
+                        lp.x[0] = h[0]; lp.x[1] = h[1]; lp.y[0] = h[2]; lp.y[1] = h[3];
+                        hp.x[0] = h[2]; hp.x[1] = h[3]; hp.y[0] = h[4]; hp.y[1] = h[5];
+                        SGs.lp[at][c] = lp;
+                        SGs.hp[at][c] = hp;
+                    }
+                }
+            } else if (FP && !RG) {
+                if (first && !filtered && lane < nch)
+                    send_history_follow_values(ctx, inst, lane, send_mask, lane == 0 ? hist_new[0] : hist_new[CH - 1], lane == 0 ? hist_old[0] : hist_old[CH - 1]);
+            } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
+        }
+        if constexpr (FP) {
+            // ---- the hot record for the next call: histories and stamp always, the tables when they were rebuilt ----
+            if (go) {
+                if (lane == 0) {
+                    miscu[hot::M_EPOCH] = epoch_now;
+                    miscu[hot::M_OFFSET] = static_cast<unsigned>(offset + frames);
+                    miscu[hot::M_MOD_F] = __float_as_uint(mod_f);
+                    miscu[hot::M_MOD_INDEX] = static_cast<unsigned>((static_cast<long long>(v_modidx) + frames) % v_modrange);
+                    miscu[hot::M_MOD_ON] = (MD && ((mod_depth != 0.0F) || (mod_f != 0.0F))) ? 1u : 0u;
+                }
+                wave_sync();
+                v4u* rec = reinterpret_cast<v4u*>(ctx.hot + sidx * hot::SIZE);
+                if (lane >= 48) rec[lane] = *reinterpret_cast<const v4u*>(miscu + 4 * (lane - 48));
+                else if (lane >= 32) rec[lane] = *reinterpret_cast<const v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32));
+                else if (!hit) rec[lane] = *reinterpret_cast<const v4u*>(utu + 4 * lane);
+            }
+        }
+    };
     for (int it = (SF && any_sf) ? -1 : 0; it <= tiles && tiles > 0; ++it) {
         const int ta = it, tb = it - 1, tc = it + 1; // tc (SF): the tile whose frame goes through the send filters in this iteration
         const bool has_a = ta >= 0 && ta < tiles, has_b = tb >= 0, has_c = SF && tc < tiles;
@@ -1519,6 +1601,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         lds_barrier();
         stamp();
         // ---------------- S5: P5(tb): late all-pass, ring writes, outputs ----------------
+        if (EH && it == tiles) hand_back();
         if (go && has_b) {
             const v2f i01 = {rowL(1, 0)[4 + lane], rowL(1, 1)[4 + lane]};
             const v2f i23 = {rowL(1, 2)[4 + lane], rowL(1, 3)[4 + lane]};
@@ -1673,77 +1756,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     }
 
     // ---- hand the state back ----
-    if (go) {
-        if (lane < 4) {
-            const float* ch = chain_all[wib][lane];
-            S.lp[lane].x[0] = ch[coop::LPX0]; S.lp[lane].x[1] = ch[coop::LPX1];
-            S.lp[lane].y[0] = ch[coop::LPY0]; S.lp[lane].y[1] = ch[coop::LPY1];
-            if (eax) {
-                S.hp[lane].x[0] = ch[coop::LPY0]; S.hp[lane].x[1] = ch[coop::LPY1];
-                S.hp[lane].y[0] = ch[coop::HPY0]; S.hp[lane].y[1] = ch[coop::HPY1];
-            }
-            S.t60[lane][0][0] = ch[coop::T60X]; S.t60[lane][0][1] = ch[coop::T60O1];
-            S.t60[lane][1][0] = ch[coop::T60O1]; S.t60[lane][1][1] = ch[coop::T60O2];
-        }
-        if (lane == 0) {
-            S.mod_index = static_cast<int>((static_cast<long long>(v_modidx) + frames) % v_modrange);
-            S.offset = offset + frames;
-            if (MD && mod_on) S.mod_filter = mod_f;
-        }
-        if (XF && xf_active) {
-            // the transition's own state: gains where the ramps left them, the fade count, the taps once they are faded in, the change
-            // marked as seen; and whether the instance ends the call settled and at rest
-            if (q_valid) {
-                if (q_stage) S.late_cur_gain[q_line][q_chan] = g_cur;
-                else S.early_cur_gain[q_line][q_chan] = g_cur;
-            }
-            const bool fade_over = fc >= OALSFX_RV_FADE_SAMPLES;
-            if (fc0 < OALSFX_RV_FADE_SAMPLES && fade_over && lane < 24) (&S.cur_early_tap[0])[lane] = static_cast<int32_t>(utu[kTapN + lane] >> 2);
-            if (lane == 0) {
-                S.fade_count = fc;
-                S.mod_range = v_modrange;
-                SS.seen_seq = SP.update_seq;
-            }
-            if (ctx.exact) {
-                const unsigned level = gains_rest_level(q_valid, g_cur, g_tgt);
-                if (lane == 0) ctx.exact[sidx] = fade_over ? level : 0u;
-            }
-        }
-        if (SF && sf) {
-            // the send filters' histories as the recurrence lanes left them (the second shelf's input history is the first one's output)
-            if (lane < kSfRows) {
-                const int sd = lane / CH, c = lane % CH, at = sd ? 1 + slot : 0;
-                if (reinterpret_cast<const int*>(sfmisc + sfm::TAB + 12 * sd)[10] & 4) {
-                    const float* h = sfmisc + sfm::HIST + 6 * lane;
-                    oalsfx_source_state& SGs = ctx.source_state[inst];
-                    oalsfx_hist_t lp, hp;
-                    lp.x[0] = h[0]; lp.x[1] = h[1]; lp.y[0] = h[2]; lp.y[1] = h[3];
-                    hp.x[0] = h[2]; hp.x[1] = h[3]; hp.y[0] = h[4]; hp.y[1] = h[5];
-                    SGs.lp[at][c] = lp;
-                    SGs.hp[at][c] = hp;
-                }
-            }
-        } else if (FP && !RG) {
-            if (first && !filtered && lane < nch)
-                send_history_follow_values(ctx, inst, lane, send_mask, lane == 0 ? hist_new[0] : hist_new[CH - 1], lane == 0 ? hist_old[0] : hist_old[CH - 1]);
-        } else if (first && !filtered && lane < nch) send_history_follow(ctx, inst, lane, nch, frames, src);
-    }
+    if (!EH) hand_back();
     if constexpr (FP) {
-        // ---- the hot record for the next call: histories and stamp always, the tables when they were rebuilt ----
-        if (go) {
-            if (lane == 0) {
-                miscu[hot::M_EPOCH] = epoch_now;
-                miscu[hot::M_OFFSET] = static_cast<unsigned>(offset + frames);
-                miscu[hot::M_MOD_F] = __float_as_uint(mod_f);
-                miscu[hot::M_MOD_INDEX] = static_cast<unsigned>((static_cast<long long>(v_modidx) + frames) % v_modrange);
-                miscu[hot::M_MOD_ON] = (MD && ((mod_depth != 0.0F) || (mod_f != 0.0F))) ? 1u : 0u;
-            }
-            wave_sync();
-            v4u* rec = reinterpret_cast<v4u*>(ctx.hot + sidx * hot::SIZE);
-            if (lane >= 48) rec[lane] = *reinterpret_cast<const v4u*>(miscu + 4 * (lane - 48));
-            else if (lane >= 32) rec[lane] = *reinterpret_cast<const v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32));
-            else if (!hit) rec[lane] = *reinterpret_cast<const v4u*>(utu + 4 * lane);
-        }
     } else
     // ---- an instance that is not in its steady state after all (the host only guesses): the general path, out of line ----
     if constexpr (NF) {
