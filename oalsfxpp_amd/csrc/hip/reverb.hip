@@ -139,6 +139,7 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 // 2048-frame calls 333.8 -> 297.6 us (-10.9 %: 37.2 us per 256 frames, 0.73 of the roofline).
 #ifndef OALSFX_CHAIN_EXP
 #define OALSFX_CHAIN_EXP 0 // experiments: 1 an agent-scope acquire behind every wait for a turn, 2 plain stores of the output frames (timing only),
+                           // 4 the word as an agent-scope release store (an L2 write-back in front of it),
                            // 8 no wait at all (negative control of tests/test_gpu_chained.py: it must fail)
 #endif
 #ifndef OALSFX_AW
@@ -1782,7 +1783,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __hip_atomic_store(ctx.turn_cu + sidx, this_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+#if OALSFX_CHAIN_EXP & 4
+        // (experiment, ADVICE round 3: the word as an agent-scope release store -- buffer_wbl2 sc1 in front of it, a write-back of this
+        // XCD's L2 per wavefront; what launches hand on is uncached and has nothing dirty there, the caller's output frames are written
+        // through: measured, profiles/r04c_instruction_diet/release_store_ab.txt)
+        if (valid && lane == 0) __hip_atomic_store(ctx.turn + sidx, ctx.turn_set, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
         if (valid && lane == 0) __hip_atomic_store(ctx.turn + sidx, ctx.turn_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
     stamp(); // state handed back
 }
