@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // call's last iteration, in front of S5 (OALSFX_EARLY_HANDBACK): every filter history is final once that iteration's chain phases are
     // through -- S5 only writes delay lines and output frames --, so the stores travel while S5 computes instead of standing between the
     // last ring store and the word that hands the instance on.
-    constexpr bool EH = OALSFX_EARLY_HANDBACK && FP && !RG && !SF && !ST; // (the ragged, send-filter and short-tap builds have no registers for it: they spill)
+    constexpr bool EH = OALSFX_EARLY_HANDBACK && FP && !SF && !ST; // (the send-filter and short-tap builds have no registers for it: they spill)
     auto hand_back = [&]() {
         if (go) {
             if (lane < 4) {
@@ -1479,7 +1479,10 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float y1 = cdat[coop::LPY0], y2 = cdat[coop::LPY1];
             const float h1 = y1, h2 = y2;
-            biquad_chain(crowI1, crowI2, La, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            // (RG: a whole tile takes the loop with the constant trip count, as every tile of the other builds does: the variable one costs
+            // the whole tiles of a ragged call a few per cent, and only the call's last tile needs it)
+            if (!RG || La == 64) biquad_chain(crowI1, crowI2, 64, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
+            else biquad_chain(crowI1, crowI2, La, cdat[coop::LP_A1], cdat[coop::LP_A2], y1, y2);
             // history prefix for the second shelf's feed-forward half (behind the recurrence: its first requests do not wait for these stores)
             crowI2[3] = h1; crowI2[2] = h2;
             cdat[coop::LPY0] = y1; cdat[coop::LPY1] = y2;
@@ -1512,7 +1515,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             float prev = cdat[coop::T60O1];
             const float before = prev;
 #ifndef OALSFX_ABLATE_T60_CHAINS // timing experiment (scripts/README: upper bound of what a parallel prefix of these sections could save; results wrong)
-            first_order_chain(crowL1, crowL2, 0, Lb, cdat[coop::T_L2], 1.0F, false, prev);
+            if (!RG || Lb == 64) first_order_chain(crowL1, crowL2, 0, 64, cdat[coop::T_L2], 1.0F, false, prev);
+            else first_order_chain(crowL1, crowL2, 0, Lb, cdat[coop::T_L2], 1.0F, false, prev);
 #endif
             crowL2[3] = before; // the second section's feed-forward half needs o1[-1]
             cdat[coop::T60O1] = prev;
@@ -1569,7 +1573,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if (duty == ((NW == 2) ? 1 : 1 + ((NW > 4) ? (it & 1) * 4 : 0)) && chain2_on && has_a) {
                 __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
                 float y1 = cdat[coop::HPY0], y2 = cdat[coop::HPY1];
-                biquad_chain(crowI1, crowI0, La, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
+                if (!RG || La == 64) biquad_chain(crowI1, crowI0, 64, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
+                else biquad_chain(crowI1, crowI0, La, cdat[coop::HP_A1], cdat[coop::HP_A2], y1, y2);
                 cdat[coop::HPY0] = y1; cdat[coop::HPY1] = y2;
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -1593,7 +1598,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             __builtin_amdgcn_s_setprio(3); // the chain is one long dependency: let it issue ahead of the siblings' it phases on this SIMD
             float prev = cdat[coop::T60O2];
 #ifndef OALSFX_ABLATE_T60_CHAINS
-            first_order_chain(crowL1, crowL1, 0, Lb, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+            if (!RG || Lb == 64) first_order_chain(crowL1, crowL1, 0, 64, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
+            else first_order_chain(crowL1, crowL1, 0, Lb, cdat[coop::T_H2], cdat[coop::T_MID], true, prev);
 #endif
             cdat[coop::T60O2] = prev;
             __builtin_amdgcn_s_setprio(0);
