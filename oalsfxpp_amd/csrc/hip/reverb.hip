@@ -389,7 +389,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                                                     SH& sh)
 {
     static_assert(!FP || CH <= 2, "the proven-steady builds: mono / stereo");
-    static_assert(!(FP && RG) || (!SF && CR == 0), "the proven ragged builds: the plain and the most general kind, no extras");
+    static_assert(!(FP && RG) || !SF, "the proven ragged builds: the plain (with or without line-aligned stores) and the most general kind");
     static_assert(!XF || (CH <= 2 && !RG && !FP && HY && MD && ST), "the cross-fading build: a variant of the most general one, mono / stereo, whole tiles");
     static_assert(!SF || (FP && !MD && !ST && NW == 4), "send filters inside: the FP plain and HY builds");
     constexpr int kSfRows = 2 * CH; // SF: rows per stage = sends (direct, this slot's auxiliary) x input channels
@@ -981,24 +981,27 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     };
     // CR: a store site's tile as whole lines (see the template parameter).  `rot`: lane L holds the value of the sample r places before
     // its own (lanes below r: of the tile's last r samples); `before`: what those lanes held a tile ago.
-    static_assert(CR == 0 || (AW && !SF && !RG), "line-aligned stores: the plain FP builds");
+    static_assert(CR == 0 || (AW && !SF), "line-aligned stores: the plain FP builds");
     auto cr_lane_before = [&](unsigned r) -> int { return ((lane - static_cast<int>(r)) & 63) << 2; };
     auto cr_rot = [&](int from4, float v) -> float { return __uint_as_float(static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(from4, static_cast<int>(__float_as_uint(v))))); };
-    auto carry_store = [&](unsigned tile4, auto ring, unsigned r, const v4f& rot, const v4f& before, bool head, bool tail) {
+    // (L: the samples the tile holds -- 64, or fewer in a ragged call's last tile, whose lanes from r + L on hold nothing to store and
+    // whose own last samples, if they reach past the window, are the lanes below r + L - 64 of `rot`)
+    auto carry_store = [&](unsigned tile4, auto ring, unsigned r, const v4f& rot, const v4f& before, bool head, bool tail, int L) {
         constexpr int rg = decltype(ring)::value;
         const v4u lo = *reinterpret_cast<const v4u*>(utu + ut::LO + 4 * rg);
         const unsigned bm = utu[ut::BMASK + rg];
         const bool held = lane < static_cast<int>(r);
+        const int rl = static_cast<int>(r) + (RG ? L : 64);
         const unsigned at = tile4 - 4u * r + 4u * static_cast<unsigned>(lane);
 #ifdef OALSFX_CR_ABLATE // timing experiment: no partial lines at the call's ends either (results wrong)
         head = tail = false;
 #endif
-        if (!(head && held)) { // (the call's first tile: the call before has written what lies in front of it)
+        if (!(head && held) && (!RG || lane < rl)) { // (the call's first tile: the call before has written what lies in front of it)
             const unsigned wp = at & bm;
             st_ring<rg>(slab_b, wp | lo.x, held ? before.x : rot.x); st_ring<rg>(slab_b, wp | lo.y, held ? before.y : rot.y);
             st_ring<rg>(slab_b, wp | lo.z, held ? before.z : rot.z); st_ring<rg>(slab_b, wp | lo.w, held ? before.w : rot.w);
         }
-        if (tail && held) { // the call's last tile: nothing comes behind it to take its last samples along
+        if (tail && (RG ? lane < rl - 64 : held)) { // the call's last tile: nothing comes behind it to take its last samples along
             const unsigned wp = (at + 256u) & bm;
             st_ring<rg>(slab_b, wp | lo.x, rot.x); st_ring<rg>(slab_b, wp | lo.y, rot.y); st_ring<rg>(slab_b, wp | lo.z, rot.z); st_ring<rg>(slab_b, wp | lo.w, rot.w);
         }
@@ -1006,11 +1009,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     // ... held back in LDS (CR == 2): site 0 main delay, 1 early all-pass, 2 early line, 3 late all-pass, 4 late line.  Lane L < r reads
     // and writes entry L of its values' rows, nobody else's: no hand-over between lanes.
     auto cr_tail = [&](int site) -> v4f* { return reinterpret_cast<v4f*>(&sh.cr_tails[CR == 2 ? wib : 0][CR == 2 ? site : 0][lane & 31][0]); }; // (one 16-byte record per lane and site)
-    auto carry_store_lds = [&](unsigned tile4, auto ring, int site, const v4f& rot, bool head, bool tail) {
+    auto carry_store_lds = [&](unsigned tile4, auto ring, int site, const v4f& rot, bool head, bool tail, int L) {
         v4f* t = cr_tail(site);
         const unsigned r = utu[ut::CR_R];
         const v4f before = *t;
-        carry_store(tile4, ring, r, rot, before, head, tail);
+        carry_store(tile4, ring, r, rot, before, head, tail, L);
         if (lane < static_cast<int>(r)) *t = rot;
     };
     v4f cr_feed = {0, 0, 0, 0}; // CR >= 1: the late feed's values of the tile before, rotated (lanes below r: its last r samples)
@@ -1216,7 +1219,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             if constexpr (CR == 2) {
                 // (the shelves' output lies in LDS rows: read r places back, no lane rotation)
                 const int from = 4 + (cr_lane_before(utu[ut::CR_R]) >> 2);
-                carry_store_lds(tile_b4, RingId<OALSFX_RV_MAIN>{}, 0, v4f{rowI(xg, 0)[from], rowI(xg, 1)[from], rowI(xg, 2)[from], rowI(xg, 3)[from]}, head_b, tail_b);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_MAIN>{}, 0, v4f{rowI(xg, 0)[from], rowI(xg, 1)[from], rowI(xg, 2)[from], rowI(xg, 3)[from]}, head_b, tail_b, Lb);
             } else if (act) store4(t4, RingId<OALSFX_RV_MAIN>{}, rowI(xg, 0)[4 + lane], rowI(xg, 1)[4 + lane], rowI(xg, 2)[4 + lane], rowI(xg, 3)[4 + lane]);
             wave_sync();
             const v4f misc = *reinterpret_cast<const v4f*>(utf + ut::MISC);
@@ -1284,8 +1287,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             scatter2(g01, g23, sx, sy);
             if constexpr (CR == 2) {
                 const int f4 = cr_lane_before(utu[ut::CR_R]);
-                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_AP>{}, 1, v4f{cr_rot(f4, g01.x), cr_rot(f4, g01.y), cr_rot(f4, g23.x), cr_rot(f4, g23.y)}, head_b, tail_b);
-                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_LINE>{}, 2, v4f{cr_rot(f4, v23.y), cr_rot(f4, v23.x), cr_rot(f4, v01.y), cr_rot(f4, v01.x)}, head_b, tail_b);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_AP>{}, 1, v4f{cr_rot(f4, g01.x), cr_rot(f4, g01.y), cr_rot(f4, g23.x), cr_rot(f4, g23.y)}, head_b, tail_b, Lb);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_EARLY_LINE>{}, 2, v4f{cr_rot(f4, v23.y), cr_rot(f4, v23.x), cr_rot(f4, v01.y), cr_rot(f4, v01.x)}, head_b, tail_b, Lb);
             } else if (act) {
                 store4(t4, RingId<OALSFX_RV_EARLY_AP>{}, g01.x, g01.y, g23.x, g23.y);
                 store4(t4, RingId<OALSFX_RV_EARLY_LINE>{}, v23.y, v23.x, v01.y, v01.x);
@@ -1318,7 +1321,7 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     const unsigned rf = utu[ut::CR_RF];
                     const int f4 = cr_lane_before(rf);
                     const v4f rot = {cr_rot(f4, r01.x), cr_rot(f4, r01.y), cr_rot(f4, r23.x), cr_rot(f4, r23.y)};
-                    carry_store(tile_b4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, rf, rot, cr_feed, head_b, tail_b);
+                    carry_store(tile_b4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, rf, rot, cr_feed, head_b, tail_b, Lb);
                     cr_feed = rot;
                 } else if (act) store4(t4 - utu[ut::FEED4], RingId<OALSFX_RV_MAIN>{}, r01.x, r01.y, r23.x, r23.y);
                 if (ST && (short_mask & 8u)) {
@@ -1653,13 +1656,13 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
             scatter2(q01, q23, sx, sy);
             if constexpr (CR == 2) {
                 const int f4 = cr_lane_before(utu[ut::CR_R]);
-                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_AP>{}, 3, v4f{cr_rot(f4, q01.x), cr_rot(f4, q01.y), cr_rot(f4, q23.x), cr_rot(f4, q23.y)}, head_b, tail_b);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_AP>{}, 3, v4f{cr_rot(f4, q01.x), cr_rot(f4, q01.y), cr_rot(f4, q23.x), cr_rot(f4, q23.y)}, head_b, tail_b, Lb);
             } else if (act) store4(t4, RingId<OALSFX_RV_LATE_AP>{}, q01.x, q01.y, q23.x, q23.y);
             v2f r01 = {l23.y, l23.x}, r23 = {l01.y, l01.x};
             scatter2(r01, r23, sx, sy);
             if constexpr (CR == 2) {
                 const int f4 = cr_lane_before(utu[ut::CR_R]);
-                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_LINE>{}, 4, v4f{cr_rot(f4, r01.x), cr_rot(f4, r01.y), cr_rot(f4, r23.x), cr_rot(f4, r23.y)}, head_b, tail_b);
+                carry_store_lds(tile_b4, RingId<OALSFX_RV_LATE_LINE>{}, 4, v4f{cr_rot(f4, r01.x), cr_rot(f4, r01.y), cr_rot(f4, r23.x), cr_rot(f4, r23.y)}, head_b, tail_b, Lb);
             } else if (act) store4(t4, RingId<OALSFX_RV_LATE_LINE>{}, r01.x, r01.y, r23.x, r23.y);
             const float data[8] = {e01.x, e01.y, e23.x, e23.y, l01.x, l01.y, l23.x, l23.y};
             if (MC) {
@@ -2577,9 +2580,11 @@ const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list
         // ragged variants of the plain and of the most general proven build (hot records, no steady-state test, no general path inside)
         if (c.channels == 1) {
             if (short_taps || modulated || close_taps) OALSFX_STEADY(1, false, true, true, true, true, true, false, 0);
+            if (carry) OALSFX_STEADY(1, false, false, false, false, true, true, false, 2);
             OALSFX_STEADY(1, false, false, false, false, true, true, false, 0);
         }
         if (short_taps || modulated || close_taps) OALSFX_STEADY(2, false, true, true, true, true, true, false, 0);
+        if (carry) OALSFX_STEADY(2, false, false, false, false, true, true, false, 2);
         OALSFX_STEADY(2, false, false, false, false, true, true, false, 0);
     }
     if (c.channels > 2) {
