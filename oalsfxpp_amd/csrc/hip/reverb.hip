@@ -145,6 +145,9 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 #ifndef OALSFX_AW
 #define OALSFX_AW 1
 #endif
+#ifndef OALSFX_CU_CHECK_BESIDE_RECORD
+#define OALSFX_CU_CHECK_BESIDE_RECORD 1 // chained launches, FP builds: the CU names of the launches before travel beside the hot record (0: in front of it, as before)
+#endif
 #ifndef OALSFX_EARLY_HANDBACK
 #define OALSFX_EARLY_HANDBACK 1 // FP builds write state and hot record in front of the last tile's S5 instead of behind the loop (0: as before, same-box A/B)
 #endif
@@ -457,6 +460,11 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
     //    instead of working on what this one skipped -- and the host, which sees the fault word at its next synchronising call, fails
     //    that call and every later one of the batch (check_fault, batch.cpp).
     unsigned cu_before = 0; // the CU the launch before ran this instance on (0: this launch is a run's first)
+    // (FP builds ask for the two CU names when the turn has come and look at them beside the hot record's load, one round trip for both
+    // instead of two in a row: OALSFX_CU_CHECK_BESIDE_RECORD)
+    unsigned v_cu1 = 0, v_cu2 = 0;
+    bool cu_check_pending = false;
+    const int dbg = flags >> 8; // test switches of the hand-over, below
     if (ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ctx.turn != nullptr && ctx.turn_wait != 0u) {
         // Test switches (OALSFX_DEBUG_FLAGS 1 / 2 / 4, tests/test_gpu_chained.py): 1 every wavefront pays for the agent-scope acquire behind
@@ -465,7 +473,6 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // state and the all-pass rings' lines it is about to use -- what the design's invariant "nobody reads an instance's lines before
         // its turn" forbids -- so that this CU's L1 holds them as they were while the launch before is still writing them: with 2 the
         // results must come out wrong (the negative control), with 1 the acquire must put them right.
-        const int dbg = flags >> 8;
         if (dbg & 4) {
             const unsigned* rec = ctx.hot + sidx * hot::SIZE;
             const unsigned* st = reinterpret_cast<const unsigned*>(ctx.state + sidx);
@@ -524,7 +531,14 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         // (buffer_inv sc1: this CU's L1 dropped).  Rare on a full chip (a workgroup is on the chip, waiting, before the one it waits for
         // leaves its CU); with few workgroups, whose places shift from launch to launch as instances change kind, it is what the random
         // runs of tests/test_gpu_chained.py found: 35 of 6000 wrong with the launch before alone looked at, three launches in flight.
-        {
+        if constexpr (FP && OALSFX_CU_CHECK_BESIDE_RECORD) {
+            if (lane == 0) {
+                v_cu1 = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v_cu2 = __hip_atomic_load(ctx.turn_cu2 + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cu_check_pending = true;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below behind the wait)
+        } else {
             unsigned before_cu = 0, before_that_cu = 0;
             if (lane == 0) {
                 before_cu = __hip_atomic_load(ctx.turn_cu + sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -544,7 +558,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         }
 #endif
         __builtin_amdgcn_s_dcache_inv();
-        __builtin_amdgcn_s_waitcnt(0);
+        if (FP && OALSFX_CU_CHECK_BESIDE_RECORD && !(OALSFX_CHAIN_EXP & 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the CU names stay in flight)
+        else __builtin_amdgcn_s_waitcnt(0);
     }
     const int l4 = lane & 3;
     const int q_stage = lane / (4 * CH), q_line = (lane / CH) & 3, q_chan = lane % CH;
@@ -586,11 +601,27 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 early_in0 = raw[fl];
             }
         }
-        epoch_now = __builtin_amdgcn_readfirstlane(ctx.inst_epoch[inst]);
-        const int offset_now = __builtin_amdgcn_readfirstlane(S.offset);
-        if (lane < 32) *reinterpret_cast<v4u*>(utu + 4 * lane) = r;
-        else if (lane < 48) *reinterpret_cast<v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32)) = r;
-        else *reinterpret_cast<v4u*>(miscu + 4 * (lane - 48)) = r;
+        unsigned v_epoch = ctx.inst_epoch[inst];
+        int v_off = S.offset;
+        v4u rr = r;
+        if (cu_check_pending) {
+            // the CU names asked for when the turn came (see the wait above): where this wavefront runs on the CU of the launch before --
+            // or of the one before that, where it may still have been at work -- this CU's L1 may hold the instance's lines as that launch
+            // read them: dropped (agent-scope acquire), and what was just loaded through it asked for again
+            const unsigned before_cu = __builtin_amdgcn_readfirstlane(v_cu1), before_that_cu = __builtin_amdgcn_readfirstlane(v_cu2);
+            cu_before = before_cu;
+            if (!(dbg & 2) && ((dbg & 1) || before_cu == this_cu() || (ctx.turn_two_back != 0u && before_that_cu == this_cu()))) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
+                rr = rec[lane];
+                v_off = S.offset;
+            }
+        }
+        epoch_now = __builtin_amdgcn_readfirstlane(v_epoch);
+        const int offset_now = __builtin_amdgcn_readfirstlane(v_off);
+        if (lane < 32) *reinterpret_cast<v4u*>(utu + 4 * lane) = rr;
+        else if (lane < 48) *reinterpret_cast<v4u*>(&chain_all[wib][0][0] + 4 * (lane - 32)) = rr;
+        else *reinterpret_cast<v4u*>(miscu + 4 * (lane - 48)) = rr;
         wave_sync();
         hit = valid && __builtin_amdgcn_readfirstlane(miscu[hot::M_EPOCH]) == epoch_now &&
               static_cast<int>(__builtin_amdgcn_readfirstlane(miscu[hot::M_OFFSET])) == offset_now;
