@@ -1443,12 +1443,17 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     bool first_on_its_stream = false; // (of the current run)
     if (chained) {
         // The streams in turn; the first launch of a run stays on the batch's stream, behind whatever was queued there before.  Two streams
-        // while every workgroup takes the same time (one kind of proven instances, nothing uploaded): the third only costs a short run its
-        // start (the driver's 20-step bench: 43.7 us per step with two, 44.9 with three).  Three when workgroups differ (several kinds,
-        // cross-fading instances): a launch then does not wait for the slowest workgroups of the launch two before it.
+        // while every workgroup takes the same time (one kind of proven instances, nothing uploaded), three when workgroups differ
+        // (several kinds, cross-fading instances): a launch then does not wait for the slowest workgroups of the launch two before it.
         int populated = 0;
         for (int k = 0; k < 3; ++k) populated += b->kind_count[0][k] > 0;
-        const int depth = (populated > 1 || b->slow_count[0] > 0 || upload.st) ? kChainDepth : std::min(2, kChainDepth);
+        // (Round 4 looked at three for the uniform workload again: the gate in front of a launch is a kernel of its own behind the launch
+        // two before it, and with two streams it starts when that launch ends, 5 us before the launch behind it can be dispatched
+        // (profiles/r04f_round4_end/chained/timeline_chained.txt); with three it is through by then.  400-call runs 40.3 -> 39.8 us per
+        // step -- and the driver's own command, bench.py --steps 20 --warmup 5, 43.0-43.7 -> 49.0-51.6: a short run pays for the third
+        // stream's start three times over.  Two it stays; OALSFX_DEBUG_FLAGS 0x10000: three.
+        // profiles/r04c_instruction_diet/chain_depth_uniform.txt)
+        const int depth = (populated > 1 || b->slow_count[0] > 0 || upload.st || (debug_flags() & 0x10000)) ? kChainDepth : std::min(2, kChainDepth);
         b->chain_pos_before = b->chain_open ? b->chain_pos_last : -1;
         b->chain_pos_last = b->chain_open ? b->chain_pos : -1;
         b->chain_pos = b->chain_open ? (b->chain_pos + 1) % depth : 0;
