@@ -1029,7 +1029,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 {
     if (b->d_mixbuf || b->slots == 1) return true;
     const size_t bytes = static_cast<size_t>(b->n) * b->channels * OALSFX_MAX_CHUNK * sizeof(float);
-    return b->hip_ok(hipMalloc(reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
+    // (handed from the reverb-free slots' launch to the reverbs' in a chained step: with the rest of what launches hand on)
+    return b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_mixbuf), bytes), "hipMalloc(mixbuf)");
 }
 
 // Timing experiments and test switches (OALSFX_DEBUG_FLAGS, or oalsfx_debug_set_flags for A/B runs inside one process): 1 / 2 / 4 the
@@ -1051,7 +1052,10 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // workgroups; measured slower: chain_eligible), 0x2000 no proven ragged builds (calls that end in a partial tile on the believing build, in stream
 // order: as before round 4), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
-// of tests/test_gpu_chained.py: it must fail).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
+// of tests/test_gpu_chained.py: it must fail), 0x40000 no chained steps of two launches (batches of several slots in stream order, as
+// before round 4), 0x100 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
+// 0x1000 a chained step's two kernels with the workgroup sizes they declare (experiment: the places one kernel's workgroups give up
+// do not fit the other's).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
 // delay lines, state and hot records live), OALSFX_HOST_PROFILE (what the host spends in prepare_params, printed by synchronize)
 std::atomic<int> g_debug_flags{-1}; // process-wide, read by every batch on whatever host thread drives it
 int debug_flags()
@@ -1379,7 +1383,7 @@ bool chain_join(oalsfx_batch* b)
 // and a step that is exactly one steady-state launch.  (Any number of workgroups: the gate in front of a launch sees to it that all but
 // a few workgroups of the launch before have started, however many rounds of the chip that launch takes -- 32 768 instances, eight
 // rounds: 380 -> 360 us per step.)
-bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream)
+bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream, bool uploading)
 {
     if (b->chain_open && b->chain_dsts.size() >= 256) {
         // (a caller that hands in a fresh output buffer with every call: the list of a run's output buffers starts over with a new run)
@@ -1400,7 +1404,21 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     if (!b->uncached) return false;
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
-    if (b->slots != 1 || b->channels > 2 || frames > OALSFX_MAX_CHUNK) return false;
+    if (b->channels > 2 || frames > OALSFX_MAX_CHUNK) return false;
+    if (b->slots > 1) {
+        // A step of two launches (round 4): every slot but the last free of reverbs for every instance -- one launch of the ring-light
+        // kernel, a wavefront per instance walking its slots -- and the last slot one grid of steady-state reverbs.  Both take turns by
+        // the same word per instance, the reverb slot's: launch after launch, whichever kernel it runs.  Whole tiles, no send filters,
+        // and nothing to upload (a call that has a change to put in place goes in stream order, and ends the run).
+        const int last = b->slots - 1;
+        if (uploading || (frames & 63) != 0 || b->n_filtered > 0 || reverb_free_run(b, 0) != last || (debug_flags() & (0x8000000 | 0x40000))) return false;
+        if ((b->n + 3) / 4 < 1024 && frames < 256 && !(debug_flags() & 0x8000)) return false;
+        if (b->fast_count[last] + b->slow_count[last] != b->n || b->general_count[last] != 0) return false;
+        KernelCtx ctx{};
+        ctx.frames = frames;
+        const SlotPlan pl = plan_slot(b, ctx, last, frames, true);
+        return pl.by_kind && !pl.mixed && pl.steady == b->n;
+    }
     // Short calls of a batch that leaves workgroup slots free gain nothing from the overlap and can lose by it: the next launch's
     // workgroups are on the chip at once, waiting, beside the ones they wait for (2048 instances x 64 frames: 16.7 us per step chained,
     // 13.4 in stream order; x 128: 22.3 against 19.5; from 256 frames on, and with every slot taken, chained is level or ahead:
@@ -1428,6 +1446,66 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     return true;
 }
 
+// The next launch of a run of chained launches: its stream, the number it waits for and the one it leaves, the gate in front of it.
+bool chain_next_launch(oalsfx_batch* b, KernelCtx& ctx, int depth, PendingUpload* upload, hipStream_t* stream_out)
+{
+    b->chain_pos_before = b->chain_open ? b->chain_pos_last : -1;
+    b->chain_pos_last = b->chain_open ? b->chain_pos : -1;
+    b->chain_pos = b->chain_open ? (b->chain_pos + 1) % depth : 0;
+    hipStream_t stream = b->chain_stream[b->chain_pos];
+    const bool first_on_its_stream = b->chain_open && !b->chain_used[b->chain_pos]; // (of the current run)
+    b->chain_used[b->chain_pos] = true;
+    const size_t total = static_cast<size_t>(b->n) * b->slots;
+    ctx.turn = b->d_turn;
+    ctx.turn_cu = b->d_turn + total + 16;
+    ctx.turn_cu2 = ctx.turn_cu + total;
+    ctx.turn_slot = b->slots - 1;
+    // (this launch sits behind the launch two before it in its stream -- two streams taking turns -- or that launch may still run)
+    ctx.turn_two_back = (b->chain_pos_before >= 0 && b->chain_pos_before != b->chain_pos) ? 1u : 0u;
+    ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
+    if (++b->turn_counter == 0u) b->turn_counter = 1u;
+    ctx.turn_set = b->turn_counter;
+    // A launch whose workgroups wait for the launch before must not take the chip before that launch has its workgroups on it: they
+    // would wait for workgroups that cannot start.  Stream order does not see to that (this launch comes behind the launch two
+    // before it, on its own stream; the launch before it sits in another queue, which the hardware may get to later -- the first
+    // launch ever on the second stream waited for its queue to be set up while the third launch of the run filled the chip).  So
+    // every workgroup of a chained launch counts itself in as it starts, and every launch but a run's first comes behind a gate
+    // (one wavefront, k_chain_gate) that waits until all but a few workgroups of the launch before have.  Then a workgroup that
+    // waits always waits for one that is on the chip or through: at most those few are not, fewer than the chip has places.
+    unsigned* started = b->d_turn + total;
+    if (!b->chain_open) {
+        if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
+        b->chain_len = 1;
+    } else {
+        // (the first launch of the run on one of the other streams: not before the run's first could start either)
+        ++b->chain_len;
+        if (first_on_its_stream && !b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
+        // (0x800: the gate in front of a run's second launch only, as first built -- the negative control of
+        // tests/test_gpu_chained.py::test_the_first_run_of_a_fresh_process)
+        if (b->chain_len == 2 || !(debug_flags() & 0x800)) {
+            const unsigned target = b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1));
+            if (upload && upload->st) { upload->jobs.gate_started = started; upload->jobs.gate_target = target; } // (the upload kernel is the gate as well)
+            else oalsfx_hip::launch_chain_gate(started, target, b->d_fault, stream);
+        }
+    }
+    ctx.turn_started = started;
+    b->chain_open = true;
+    b->launched_groups = 0;
+    *stream_out = stream;
+    return true;
+}
+
+// ... and behind it: every workgroup of the launch counts itself in on the device (reverb.hip, turn_started): the grid as launched, which
+// for a grid of several kinds is up to three workgroups more than a quarter of the instances (ADVICE, round 3: the host added (n + 3) / 4
+// and drifted behind the device's count by up to three per call).
+bool chain_launch_done(oalsfx_batch* b)
+{
+    if (b->launched_groups <= 0) return b->fail("Internal error: a chained call launched no grid that takes turns.");
+    b->started_total += static_cast<uint32_t>(b->launched_groups);
+    b->launched_groups = 0;
+    return true;
+}
+
 bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipStream_t stream, bool may_chain = false)
 {
     if (b->poisoned) return b->fail(b->fault_text);
@@ -1438,28 +1516,23 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     const auto hp0 = std::chrono::steady_clock::now();
     if (!prepare_params(b, upload)) return false;
     b->host_prepare_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hp0).count();
-    const bool chained = may_chain && (!upload.st || upload.chainable) && chain_eligible(b, frames, src, dst, stream);
+    const bool chained = may_chain && (!upload.st || upload.chainable) && chain_eligible(b, frames, src, dst, stream, upload.st != nullptr);
     if (!chained && !chain_join(b)) return false;
-    bool first_on_its_stream = false; // (of the current run)
+    int depth = 2;
     if (chained) {
         // The streams in turn; the first launch of a run stays on the batch's stream, behind whatever was queued there before.  Two streams
         // while every workgroup takes the same time (one kind of proven instances, nothing uploaded), three when workgroups differ
         // (several kinds, cross-fading instances): a launch then does not wait for the slowest workgroups of the launch two before it.
+        const int rs = b->slots - 1; // (the reverbs' slot)
         int populated = 0;
-        for (int k = 0; k < 3; ++k) populated += b->kind_count[0][k] > 0;
+        for (int k = 0; k < 3; ++k) populated += b->kind_count[rs][k] > 0;
         // (Round 4 looked at three for the uniform workload again: the gate in front of a launch is a kernel of its own behind the launch
         // two before it, and with two streams it starts when that launch ends, 5 us before the launch behind it can be dispatched
         // (profiles/r04f_round4_end/chained/timeline_chained.txt); with three it is through by then.  400-call runs 40.3 -> 39.8 us per
         // step -- and the driver's own command, bench.py --steps 20 --warmup 5, 43.0-43.7 -> 49.0-51.6: a short run pays for the third
         // stream's start three times over.  Two it stays; OALSFX_DEBUG_FLAGS 0x10000: three.
         // profiles/r04c_instruction_diet/chain_depth_uniform.txt)
-        const int depth = (populated > 1 || b->slow_count[0] > 0 || upload.st || (debug_flags() & 0x10000)) ? kChainDepth : std::min(2, kChainDepth);
-        b->chain_pos_before = b->chain_open ? b->chain_pos_last : -1;
-        b->chain_pos_last = b->chain_open ? b->chain_pos : -1;
-        b->chain_pos = b->chain_open ? (b->chain_pos + 1) % depth : 0;
-        stream = b->chain_stream[b->chain_pos];
-        first_on_its_stream = b->chain_open && !b->chain_used[b->chain_pos];
-        b->chain_used[b->chain_pos] = true;
+        depth = (populated > 1 || b->slow_count[rs] > 0 || upload.st || (debug_flags() & 0x10000)) ? kChainDepth : std::min(2, kChainDepth);
     }
     if (!chained && !launch_params(b, upload, b->stream, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
@@ -1469,6 +1542,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     const size_t plane = static_cast<size_t>(b->n) * chunk_max * b->channels;
     if (filtered && plane > b->filtered_capacity) {
         if (!b->hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return false;
+        for (int k = 1; k < kChainDepth && b->chain_open; ++k) // (a run of chained launches: the planes' readers may be on its other streams)
+            if (!b->hip_ok(hipStreamSynchronize(b->chain_stream[k]), "hipStreamSynchronize")) return false;
         hipFree(b->d_filtered);
         b->d_filtered = nullptr;
         b->filtered_capacity = 0;
@@ -1490,22 +1565,6 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     ctx.list_first = -1;
     ctx.no_follow_up = 0;
     if (chained) {
-        ctx.turn = b->d_turn;
-        ctx.turn_cu = b->d_turn + static_cast<size_t>(b->n) * b->slots + 16;
-        ctx.turn_cu2 = ctx.turn_cu + static_cast<size_t>(b->n) * b->slots;
-        // (this launch sits behind the launch two before it in its stream -- two streams taking turns -- or that launch may still run)
-        ctx.turn_two_back = (b->chain_pos_before >= 0 && b->chain_pos_before != b->chain_pos) ? 1u : 0u;
-        ctx.turn_wait = b->chain_open ? b->turn_counter : 0u;
-        if (++b->turn_counter == 0u) b->turn_counter = 1u;
-        ctx.turn_set = b->turn_counter;
-        // A launch whose workgroups wait for the launch before must not take the chip before that launch has its workgroups on it: they
-        // would wait for workgroups that cannot start.  Stream order does not see to that (this launch comes behind the launch two
-        // before it, on its own stream; the launch before it sits in another queue, which the hardware may get to later -- the first
-        // launch ever on the second stream waited for its queue to be set up while the third launch of the run filled the chip).  So
-        // every workgroup of a chained launch counts itself in as it starts, and every launch but a run's first comes behind a gate
-        // (one wavefront, k_chain_gate) that waits until all but a few workgroups of the launch before have.  Then a workgroup that
-        // waits always waits for one that is on the chip or through: at most those few are not, fewer than the chip has places.
-        unsigned* started = b->d_turn + static_cast<size_t>(b->n) * b->slots;
         {
             const char* lo = reinterpret_cast<const char*>(dst);
             const char* hi = lo + static_cast<size_t>(b->n) * frames * b->channels * sizeof(float);
@@ -1514,33 +1573,23 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
             for (auto& d : b->chain_dsts) known |= d.first <= lo && hi <= d.second;
             if (!known) b->chain_dsts.push_back({lo, hi});
         }
-        if (!b->chain_open) {
-            if (!b->hip_ok(hipEventRecord(b->ev_chain_start, b->stream), "hipEventRecord")) return false;
-            b->chain_len = 1;
-        } else {
-            // (the first launch of the run on one of the other streams: not before the run's first could start either)
-            ++b->chain_len;
-            if (first_on_its_stream && !b->hip_ok(hipStreamWaitEvent(stream, b->ev_chain_start, 0), "hipStreamWaitEvent")) return false;
-            // (0x800: the gate in front of a run's second launch only, as first built -- the negative control of
-            // tests/test_gpu_chained.py::test_the_first_run_of_a_fresh_process)
-            if (b->chain_len == 2 || !(debug_flags() & 0x800)) {
-                const unsigned target = b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1));
-                if (upload.st) { upload.jobs.gate_started = started; upload.jobs.gate_target = target; } // (the upload kernel is the gate as well)
-                else oalsfx_hip::launch_chain_gate(started, target, b->d_fault, stream);
-            }
-        }
-        ctx.turn_started = started;
+        // the step's first launch (of two, for a batch of several slots: chain_eligible)
+        if (!chain_next_launch(b, ctx, depth, &upload, &stream)) return false;
         // Parameters that changed since the call before: put in place on this launch's stream, behind the gate -- beside the launch
         // before, which may still be at work with the old ones: a slot's record (and its instance's epoch) is stored once that launch is
         // through with the instance; a rebuilt list went to the buffer that launch does not read.
         if (!launch_params(b, upload, stream, nullptr, b->d_turn, ctx.turn_wait)) return false;
-        b->chain_open = true;
         b->chained_calls += 1;
     }
     ctx.slots = b->slots;
     ctx.channels = b->channels;
     ctx.io_stride = static_cast<long long>(frames) * b->channels;
-    b->launched_groups = 0;
+    // (a chained step of two kernels: workgroups of one size, so that either kernel's fit the places the other's give up -- common.hpp)
+    struct EqualPlaces {
+        bool on;
+        explicit EqualPlaces(bool o) : on(o) { if (on) oalsfx_hip::set_lds_per_workgroup(40960); }
+        ~EqualPlaces() { if (on) oalsfx_hip::set_lds_per_workgroup(0); }
+    } equal_places(chained && b->slots > 1 && !(debug_flags() & 0x1000));
     // Api::mix chunking (reference src/oalsfxpp.cpp:3818-3826)
     for (int done = 0; done < frames;) {
         const int n = std::min(frames - done, OALSFX_MAX_CHUNK);
@@ -1593,11 +1642,18 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                                       (planes ? oalsfx_hip::kFiltered : 0);
                 {
                     ScopedTiming timing(b, kTimedWaveEffects, stream);
-                    oalsfx_hip::launch_wave_effects(ctx, s, run, b->d_lists + b->list_offset[s][OALSFX_NULL], b->n, nullptr, run_flags, stream);
+                    // (a chained step: in the order of the reverbs' grid -- its list names every instance once as well)
+                    const bool grid_order = chained && !(debug_flags() & 0x100);
+                    const int* every = grid_order ? b->d_lists + b->steady_offset[b->slots - 1] : b->d_lists + b->list_offset[s][OALSFX_NULL];
+                    oalsfx_hip::launch_wave_effects(ctx, s, run, every, b->n, nullptr,
+                                                    run_flags | (chained ? ((debug_flags() & 3) | (grid_order ? 0 : 8)) << 8 : 0), stream);
                 }
+                if (chained) b->launched_groups = (b->n + 3) / 4;
                 s += run - 1;
                 continue;
             }
+            // (a chained step's second launch: the reverbs' grid, next in the run)
+            if (chained && s > 0 && (!chain_launch_done(b) || !chain_next_launch(b, ctx, depth, nullptr, &stream))) return false;
             const int flags = (s == 0 ? oalsfx_hip::kFirst : 0) | (s == b->slots - 1 ? oalsfx_hip::kLast : 0) |
                               (planes ? oalsfx_hip::kFiltered : 0);
             const bool null_has_duty = (flags & (oalsfx_hip::kFirst | oalsfx_hip::kLast)) != 0;
@@ -1648,13 +1704,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         }
         done += n;
     }
-    if (chained) {
-        // every workgroup of the launch counts itself in on the device (reverb.hip, turn_started): the grid as launched, which for a grid
-        // of several kinds is up to three workgroups more than a quarter of the instances (ADVICE, round 3: the host added (n + 3) / 4
-        // and drifted behind the device's count by up to three per call)
-        if (b->launched_groups <= 0) return b->fail("Internal error: a chained call launched no steady-state grid.");
-        b->started_total += static_cast<uint32_t>(b->launched_groups);
-    }
+    if (chained && !chain_launch_done(b)) return false;
     if ((frames % OALSFX_MAX_CHUNK) & 63) {
         // a ragged chunk: a cross-fade in flight no longer stands at a tile boundary, which the XF build needs
         for (size_t idx : b->settling)
@@ -1746,7 +1796,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     {
         // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
         const char* kind = std::getenv("OALSFX_RING_MEMORY");
-        b->uncached = effect_count == 1 && b->channels <= 2 &&
+        b->uncached = b->channels <= 2 &&
                       (!kind || std::strcmp(kind, "uncached") == 0) && uncached_memory_available(b->device);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
@@ -1820,7 +1870,7 @@ void oalsfx_batch_destroy(oalsfx_batch* b)
                      b->host_prepare_ns * 1e-6, b->host_stage_wait_ns * 1e-6, b->chained_calls);
     for (void* c : b->chunks) handed_on_free(c);
     hipFree(b->d_params); handed_on_free(b->d_state); hipFree(b->d_source); hipFree(b->d_rings); handed_on_free(b->d_source_state); hipFree(b->d_filtered);
-    hipFree(b->d_mixbuf); hipFree(b->d_lists_buf[0]); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
+    handed_on_free(b->d_mixbuf); hipFree(b->d_lists_buf[0]); hipFree(b->d_progress); hipFree(b->d_io_src); hipFree(b->d_io_dst);
     handed_on_free(b->d_hot); hipFree(b->d_inst_epoch); handed_on_free(b->d_exact); handed_on_free(b->d_turn);
     for (int k = 1; k < kChainDepth; ++k)
         if (b->ev_chain[k]) hipEventDestroy(b->ev_chain[k]);

@@ -62,6 +62,8 @@ struct KernelCtx {
     unsigned* turn_cu2;                 // ... and the one before it
     unsigned turn_two_back;             // != 0: the launch before the last may still have been at work when this launch started (it is not
                                         // the launch this one sits behind in its stream)
+    int turn_slot;                      // a step of several launches (batch.cpp: the reverb-free slots' launch, then the reverb slot's): the slot
+                                        // whose word every launch of the step takes turns by -- the reverb's own (it indexes by its slot)
     int list_first;                     // >= 0: the launch's list is the range list_first, list_first + 1, ... (no list load); -1: read the list
     int no_follow_up;        // hand-over launches (ctx.progress): the first no_follow_up entries of the list are proven steady and the general kernel
                               // will not be run on them; one that is not steady after all is counted in `fault`
@@ -189,9 +191,34 @@ void launch_ring_probe(float* slabs, int instances, size_t slab_floats, unsigned
 void launch_stream_pattern(float* slabs, int instances, int dwords_per_lane, unsigned pos0, size_t slab_floats, int pos_skew, hipStream_t stream);
 void launch_hbm_sweep(float* buf, size_t floats, int write, float* sink, hipStream_t stream);
 
+// Launches of this host thread from here on ask for as much LDS per workgroup as this many bytes (0: what the kernel declares).  A step of
+// two different kernels whose launches overlap (batch.cpp: chain_eligible) needs workgroups of one size: a CU hands out LDS in contiguous
+// blocks (and registers likewise: equal_places below), and a workgroup of one kernel does not fit the hole a smaller one of the other
+// left -- measured: the ring-light kernel with three of its four workgroups per CU on the chip, 113 us per step instead of 94.
+void set_lds_per_workgroup(int bytes);
+int lds_per_workgroup();
+
 #if defined(__HIPCC__)
 
-#define OALSFX_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+template <class K> inline int declared_lds(K kernel)
+{
+    hipFuncAttributes a{};
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) == hipSuccess ? static_cast<int>(a.sharedSizeBytes) : 0;
+}
+
+#define OALSFX_LAUNCH(kernel, grid, block, stream, ...)                                                          \
+    do {                                                                                                         \
+        int more_lds_ = 0;                                                                                       \
+        if (oalsfx_hip::lds_per_workgroup() > 0) {                                                               \
+            static const int declared_ = oalsfx_hip::declared_lds(kernel);                                       \
+            more_lds_ = oalsfx_hip::lds_per_workgroup() > declared_ ? oalsfx_hip::lds_per_workgroup() - declared_ : 0; \
+        }                                                                                                        \
+        hipLaunchKernelGGL(kernel, grid, block, more_lds_, stream, __VA_ARGS__);                                 \
+    } while (0)
+
+// A kernel whose wavefronts must take up exactly 128 registers, whatever the build needs (see set_lds_per_workgroup): the last statement
+// of the kernel, where nothing is live (as the first it cost several builds a spill).
+#define OALSFX_EQUAL_PLACES() asm volatile("" ::: "v127")
 
 // A grid whose workgroups run different code (k_reverb_steady_kinds: one build per kind of instance; the ring-light grids: one body per
 // effect type) is ordered by kind, and consecutive workgroups land on consecutive CUs: workgroup g of a grid of 256-thread workgroups
@@ -214,6 +241,67 @@ __device__ __forceinline__ int cu_major_position(int g, int total)
 }
 
 __device__ __forceinline__ bool audible(float g) { return fabsf(g) > OALSFX_SILENCE_GAIN; }
+
+// The CU this wavefront runs on: XCC_ID, and shader engine / array / CU of HW_ID; never 0.
+__device__ __forceinline__ unsigned this_cu()
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    return 0x10000u | ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
+}
+
+// Chained launches for a kernel with one wavefront per instance (wave_effects.hip); the rules, and why each step is there, are written
+// down where the steady-state reverb kernel does the same by hand (reverb.hip, "Chained launches").  turn_take: waits until the
+// launch before is through with the instance whose word is turn[word]; false when the turn never came (counted in the fault word: the
+// wavefront must then leave the instance alone, word included).  Nothing of the instance may be read before it returns.
+// dbg: the test switches 1 (always pay for the acquire) and 2 (never).
+__device__ __forceinline__ bool turn_take(const KernelCtx& ctx, size_t word, int lane, int dbg, unsigned& cu_before)
+{
+    cu_before = 0;
+    if (ctx.turn == nullptr || ctx.turn_wait == 0u) return true;
+    int lost = 0;
+    if (lane == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctx.turn + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ctx.turn_wait) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 20)) {
+                if (ctx.fault) __hip_atomic_fetch_add(ctx.fault, kFaultTurn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                lost = 1;
+                break;
+            }
+        }
+    }
+    if (__builtin_amdgcn_readfirstlane(lost)) return false;
+    unsigned before_cu = 0, before_that_cu = 0;
+    if (lane == 0) {
+        before_cu = __hip_atomic_load(ctx.turn_cu + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        before_that_cu = __hip_atomic_load(ctx.turn_cu2 + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    before_cu = __builtin_amdgcn_readfirstlane(before_cu);
+    before_that_cu = __builtin_amdgcn_readfirstlane(before_that_cu);
+    cu_before = before_cu;
+    if (!(dbg & 2) && ((dbg & 1) || before_cu == this_cu() || (ctx.turn_two_back != 0u && before_that_cu == this_cu()))) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (ctx.turn_started != nullptr && lane == 0) __hip_atomic_fetch_add(ctx.turn_started + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (a count for the records)
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads behind the wait)
+    }
+    __builtin_amdgcn_s_dcache_inv();
+    __builtin_amdgcn_s_waitcnt(0);
+    return true;
+}
+
+// ... and hands the instance on: every store of the wavefront acknowledged, then the CU names, then the word.
+__device__ __forceinline__ void turn_hand_on(const KernelCtx& ctx, size_t word, int lane, unsigned cu_before)
+{
+    if (ctx.turn == nullptr || ctx.turn_set == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+        __hip_atomic_store(ctx.turn_cu2 + word, cu_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctx.turn_cu + word, this_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+    if (lane == 0) __hip_atomic_store(ctx.turn + word, ctx.turn_set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ float lerpf(float a, float b, float mu) { return a + ((b - a) * mu); }
 

@@ -363,13 +363,6 @@ struct SteadyShared {
 // and a buffer starts from the instance's hot record (namespace hot): one 16-byte load per lane instead of a tree of descriptor
 // loads.  A record whose stamp does not match is rebuilt from the descriptors (first call after a promotion, or after another
 // kernel advanced the instance); an instance that then fails the steady-state test after all is counted in ctx.fault and left alone.
-// The CU this wavefront runs on: XCC_ID, and shader engine / array / CU of HW_ID; never 0.
-__device__ __forceinline__ unsigned this_cu()
-{
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    return 0x10000u | ((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu);
-}
-
 // CR (the plain FP builds: every tap three tiles away, early taps and late-line offsets 32 samples more -- kPlainMinTapAhead): ring stores
 // that cover whole 128-byte lines.  A tile's 64 samples of a ring line are 256 contiguous bytes, but where they start is the delay
 // line's write position: after a call that was not a multiple of 32 frames every such store begins and ends inside a line, for the rest
@@ -1840,6 +1833,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST, SF, CR> sh;
     reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+    if constexpr (!(RG && CR == 2 && CH == 2)) OALSFX_EQUAL_PLACES(); // (that build takes 128 registers as it is, and spilled with the statement)
 }
 
 // One grid for a slot's steady reverbs of several kinds (mono / stereo, whole tiles).  The host orders the slot's list by kind and the

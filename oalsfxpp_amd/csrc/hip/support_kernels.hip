@@ -6,6 +6,10 @@
 
 namespace oalsfx_hip {
 
+namespace { thread_local int t_lds_per_workgroup = 0; }
+void set_lds_per_workgroup(int bytes) { t_lds_per_workgroup = bytes; }
+int lds_per_workgroup() { return t_lds_per_workgroup; }
+
 // Send shelf filters as a pre-pass (reference apply_filters, src/oalsfxpp.cpp:3101-3143, called from mix_source :2929-2965).
 // A wavefront takes two consecutive instances (one where its lanes or LDS rows do not reach: a recurrence per send and input
 // channel); the instances without a filter switched on are skipped -- the effect kernels read the raw input for them and keep

@@ -8,14 +8,16 @@ namespace oalsfx_hip {
 // is one launch (the slots still accumulate in order, through mixbuf, by the same wavefront).
 // 4096 instances are 1024 workgroups, four per compute unit: one round of the chip only while a wavefront keeps to 128 registers
 // (at 133 the same grid took a second round and every effect type was 1.5 - 1.7 times slower), hence the occupancy bound.
-template <int CH>
+template <int CH, bool CHN>
 __global__ __launch_bounds__(256, CH == 8 ? 2 : 4) void k_wave_effects(KernelCtx ctx, int slot, int slot_count, const int* __restrict__ list, int count, WaveSegments seg,
                                                       int flags)
 {
     __shared__ __attribute__((aligned(16))) float lds_all[4][wfx::kLdsFloats];
-    wfx::wave_block<CH>(ctx, slot, slot_count, list, count, seg, flags, static_cast<int>(blockIdx.x), &lds_all[0][0], wfx::kLdsFloats);
+    wfx::wave_block<CH, CHN>(ctx, slot, slot_count, list, count, seg, flags, static_cast<int>(blockIdx.x), &lds_all[0][0], wfx::kLdsFloats);
+    if constexpr (CH == 1) OALSFX_EQUAL_PLACES(); // (the stereo build takes 128 registers as it is, and spilled with the statement)
 }
 
+// ctx.turn != nullptr: a launch of a run of chained launches (mono / stereo, no segments): the build whose wavefronts take turns.
 void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, const WaveSegments* seg, int flags,
                          hipStream_t stream)
 {
@@ -23,9 +25,14 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const i
     WaveSegments s{};
     if (seg && slot_count == 1) s = *seg;
     const dim3 grid(s.n > 0 ? s.blocks() : (count + 3) / 4), block(256);
-    if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
-    else if (ctx.channels == 2) OALSFX_LAUNCH((k_wave_effects<2>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
-    else OALSFX_LAUNCH((k_wave_effects<8>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
+    if (ctx.turn != nullptr && s.n == 0 && ctx.channels <= 2) {
+        if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1, true>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
+        else OALSFX_LAUNCH((k_wave_effects<2, true>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
+        return;
+    }
+    if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1, false>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
+    else if (ctx.channels == 2) OALSFX_LAUNCH((k_wave_effects<2, false>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
+    else OALSFX_LAUNCH((k_wave_effects<8, false>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
 }
 
 } // namespace oalsfx_hip

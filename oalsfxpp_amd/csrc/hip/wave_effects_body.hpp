@@ -982,12 +982,15 @@ __device__ __forceinline__ void wave_slots(const KernelCtx& ctx, int slot, int s
 // The ring-light part of a grid: workgroup `block` of it, four wavefronts.  With segments (a single slot), the blocks follow
 // the slot's type-sorted list segment by segment, so that a workgroup holds one effect type; without, wavefront w takes
 // list[w].
-template <int CH>
+// CHN: a launch of a run of chained launches (batch.cpp; no segments): the workgroup counts itself in, and a wavefront takes its
+// instance when the launch before is through with it and hands it on behind its last store (common.hpp: turn_take, turn_hand_on).
+template <int CH, bool CHN = false>
 __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int slot_count, const int* __restrict__ list, int count,
                                            const WaveSegments& seg, int flags, int block, float* lds_group, int lds_stride)
 {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (CHN && ctx.turn_started != nullptr && threadIdx.x == 0) __hip_atomic_fetch_add(ctx.turn_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Group group{false, wib, block & 3, lds_group, lds_stride};
     int w = block * 4 + wib;
     if (seg.n > 0) {
@@ -1001,11 +1004,19 @@ __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int s
         group.coop = ((seg.coop_mask >> k) & 1u) != 0;
         if (local >= seg.count[k]) return; // never in a cooperative segment: those hold whole workgroups only
         w = seg.offset[k] + local;
-    } else if (w >= count) {
-        return; // whole wavefronts leave; no workgroup barrier on this path
+    } else {
+        // (a chained step: the list is the reverbs' grid's, and so is the order -- cu_major_position: an instance's wavefront of this launch
+        // then comes up for a place on the chip when its workgroup of the reverbs' launch before gives one up, with its turn; in list order
+        // the workgroups sat waiting for turns far down that grid's order, half the chip idle: 113 us per step instead of 94 in stream order)
+        if (CHN && !((flags >> 8) & 8)) w = cu_major_position(block, (count + 3) >> 2) * 4 + wib; // (8: the experiment that takes the list as it comes)
+        if (w >= count) return; // whole wavefronts leave; no workgroup barrier on this path
     }
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
+    unsigned cu_before = 0;
+    const size_t word = static_cast<size_t>(inst) * ctx.slots + ctx.turn_slot;
+    if (CHN && !turn_take(ctx, word, lane, flags >> 8, cu_before)) return; // (its turn never came: the instance is left as it is)
     wave_slots<CH>(ctx, slot, slot_count, inst, flags, lds_group + wib * lds_stride, lane, group);
+    if (CHN) turn_hand_on(ctx, word, lane, cu_before);
 }
 
 } // namespace wfx

@@ -9,7 +9,7 @@ import csv, glob, os
 O = os.environ["O"]
 f = glob.glob(O + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if "steady" in r["Kernel_Name"] or "gate" in r["Kernel_Name"]]
+rows = [r for r in rows if "steady" in r["Kernel_Name"] or "gate" in r["Kernel_Name"] or "wave_effects" in r["Kernel_Name"]]
 tail = rows[-40:]
 t0 = int(tail[0]["Start_Timestamp"])
 with open(O + "/timeline.txt", "w") as out:

@@ -719,3 +719,127 @@ def test_short_calls_of_small_batches_stay_in_stream_order():
                     assert b.chained_calls - before == chained, (n, frames, b.chained_calls - before)
     finally:
         so.oalsfx_debug_set_flags(base | CHAIN_ALWAYS)
+
+
+# ---- steps of two launches: a run of reverb-free slots, then the reverbs' slot (round 4) ----
+
+LIGHT_TYPES = [desc.CHORUS, desc.FLANGER, desc.ECHO, desc.EQUALIZER, desc.DISTORTION, desc.RING_MODULATOR, desc.COMPRESSOR,
+               desc.DEDICATED_DIALOG, desc.DEDICATED_LFE, desc.NULL]
+
+
+def _chains_of_four(b, n, seed, uniform=False):
+    """Slots 0 .. 2: ring-light effects (the same three for every instance, or any of the ten types with random properties); slot 3: an
+    EAX reverb or a reverb, preset by preset."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect
+    rng = random.Random(seed)
+    for s in range(3):
+        if uniform:
+            b.set_effect_type(s, (desc.CHORUS, desc.FLANGER, desc.ECHO)[s])
+        else:
+            b.set_effect(s, [random_effect(rng, LIGHT_TYPES[rng.randrange(len(LIGHT_TYPES))]) for _ in range(n)])
+    if uniform:
+        b.set_effect_type(3, desc.EAX_REVERB)
+    else:
+        b.set_effect(3, [preset_effect((5 * i) % 113, desc.EAX_REVERB if i % 3 else desc.REVERB) for i in range(n)])
+    b.apply_changes()
+
+
+def _a_run_of_steps_of_two_launches(n, fmt, seed, script, expect_chained):
+    with Batch(n, fmt, 48000, 4) as b:
+        _chains_of_four(b, n, seed)
+        picks = sorted(set([0, 1, 2, 3, n // 2, n - 2, n - 1] + list(range(5, n, max(1, n // 9)))))
+        shadows = {i: OracleShadow(b, i) for i in picks}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)                    # through the reverbs' start-up cross-fade; proven
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        run_device_calls(b, script, shadows, seed, replicas=False)
+        assert b.chained_calls - before >= expect_chained, (before, b.chained_calls)
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_steps_of_two_launches_match_the_oracle(fmt):
+    """A batch of four slots whose first three hold no reverb: a step is the ring-light kernel's launch (one wavefront per instance walks
+    the three slots) and the reverbs' grid, and consecutive steps overlap launch by launch -- both kernels take turns by the same word per
+    instance.  72 instances, every ring-light type with random properties, reverb presets; calls of 64 to 2048 frames."""
+    _a_run_of_steps_of_two_launches(72, fmt, 41000, [256] * 24 + [64, 128, 512, 2048, 256, 256], 30)
+
+
+def test_steps_of_two_launches_at_full_size():
+    _a_run_of_steps_of_two_launches(4096, desc.FMT_STEREO, 42000, [256] * 40, 40)
+
+
+@pytest.mark.parametrize("n", [70, 4096])
+def test_steps_of_two_launches_with_the_same_cu_path_taken_by_every_wavefront(n):
+    _with_debug_flags(1, lambda: _a_run_of_steps_of_two_launches(n, desc.FMT_STEREO, 43000, [256] * 24, 24))
+
+
+def test_a_run_of_steps_of_two_launches_ends_for_a_change_and_starts_again():
+    """A call that has a parameter change to put in place goes in stream order (the two-launch step does not take uploads into the run),
+    and the calls behind it chain again."""
+    n = 72
+    with Batch(n, desc.FMT_STEREO, 48000, 4) as b:
+        _chains_of_four(b, n, 44000)
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 5, 17, 35, 36, 70, 71)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+
+        def a_new_echo():
+            b.set_effect(2, [E(desc.ECHO, delay=0.05 + 0.001 * (i % 50), feedback=0.3) for i in range(n)])
+            b.apply_changes()
+
+        def a_new_send_gain():
+            b.set_send_props(-1, 0.5, 1.0, 1.0)
+            b.apply_changes()
+
+        before = b.chained_calls
+        run_device_calls(b, [256] * 6 + [a_new_echo] + [256] * 6 + [a_new_send_gain] + [256] * 6, shadows, 44000)
+        assert b.chained_calls - before >= 12, (before, b.chained_calls)
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+def test_every_instance_of_configs_2_through_consecutive_steps_of_two_launches():
+    """BASELINE configs[2] (chorus -> flanger -> echo -> EAX reverb, defaults) at full size: every one of 4096 instances with an input of
+    its own, followed by an oracle of its own through eight consecutive chained steps, each into an output buffer of its own."""
+    import torch
+    from harness import ShadowArmy
+    n, frames, calls = 4096, 256, 8
+    with Batch(n, desc.FMT_STEREO, 48000, 4) as b:
+        _chains_of_four(b, n, 0, uniform=True)
+        army = ShadowArmy(b)
+        army.sync()
+        warm = np.stack([orc.synth(45000 + i, 99, frames * 2).reshape(frames, 2) for i in range(n)])
+        for _ in range(3):
+            b.mix(warm)
+            army.mix(warm)
+        xs = [np.stack([orc.synth(45000 + i, k, frames * 2).reshape(frames, 2) for i in range(n)]) for k in range(calls)]
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = [torch.empty_like(d) for d in dx]
+        torch.cuda.synchronize()
+        before = b.chained_calls
+        for k in range(calls):
+            b.mix_device(frames, dx[k].data_ptr(), dy[k].data_ptr())
+        b.synchronize()
+        assert b.chained_calls - before == calls
+        for k in range(calls):
+            ref = army.mix(xs[k])
+            bad = army.differing(dy[k].cpu().numpy(), ref)
+            assert not bad, f"call {k}: {len(bad)} instances differ, the first {bad[:6]}"
+        for s in army.shadows[::97]:
+            d = s.compare_state()
+            assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
