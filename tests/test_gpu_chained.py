@@ -758,8 +758,13 @@ def _a_run_of_steps_of_two_launches(n, fmt, seed, script, expect_chained):
             for s in shadows.values():
                 s.oracle.mix(warm[0])
         before = b.chained_calls
+        h0, d0 = b.chain_started()
         run_device_calls(b, script, shadows, seed, replicas=False)
         assert b.chained_calls - before >= expect_chained, (before, b.chained_calls)
+        # the gates' count: both launches of a step add their workgroups, on the host and on the device
+        h1, d1 = b.chain_started()
+        assert h1 == d1, f"host {h1} and device {d1} disagree"
+        assert (h1 - h0) % (1 << 32) >= 2 * (b.chained_calls - before) * ((n + 3) // 4)
         for i, s in shadows.items():
             d = s.compare_state()
             assert not d, f"instance {i}: " + "; ".join(d[:12])

@@ -45,6 +45,18 @@ def test_four_workgroups_per_cu_fit():
         assert r["lds"] <= 40960, f"{name}: {r['lds']} B of LDS: three workgroups per CU instead of four"
 
 
+def test_the_kernels_of_a_chained_run_take_places_of_one_size():
+    """A run of chained launches may alternate between two kernels (a step of two launches: the ring-light kernel, then the reverbs' grid):
+    a CU hands out registers in contiguous blocks, and a 128-register wavefront does not fit the place a 120-register one gave up (measured:
+    113 us per step instead of 89).  Every mono / stereo build of the kernels that take turns allocates exactly 128 (OALSFX_EQUAL_PLACES);
+    their LDS is made equal at launch time (set_lds_per_workgroup: at most 40 960 B declared, see the test above)."""
+    ks = kernels()
+    grids = {k: v for k, v in ks.items() if k.startswith(("k_reverb_steady_coop<1", "k_reverb_steady_coop<2", "k_reverb_steady_kinds", "k_wave_effects<1,", "k_wave_effects<2,"))}
+    assert len(grids) >= 30, sorted(ks)
+    for name, r in grids.items():
+        assert r["vgpr"] == 128, f"{name}: {r['vgpr']} registers"
+
+
 def test_the_proven_builds_carry_no_scratch():
     """The FP builds have no general path inside and must not spill to memory (template arguments: channels, wavefronts, TL, HY, MD,
     ST, RG, FP, ...)."""
