@@ -1054,6 +1054,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
 // of tests/test_gpu_chained.py: it must fail), 0x40000 no chained steps of two launches (batches of several slots in stream order, as
 // before round 4), 0x100 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
+// 0x80 batches without any reverb chain their calls too (tests of the ring-light kernel's hand-over; measured slower: chain_eligible),
 // 0x1000 a chained step's two kernels with the workgroup sizes they declare (experiment: the places one kernel's workgroups give up
 // do not fit the other's).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
 // delay lines, state and hot records live), OALSFX_HOST_PROFILE (what the host spends in prepare_params, printed by synchronize)
@@ -1269,7 +1270,16 @@ void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     const int count = wave_segments(b, slot, first_type, seg);
     if (count == 0) return;
     ScopedTiming timing(b, kTimedWaveEffects, stream);
+    if (ctx.turn != nullptr) { flags |= (debug_flags() & 3) << 8; b->launched_groups += seg.blocks(); } // (a chained launch: test switches, the gate's count)
     oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, &seg, flags, stream);
+}
+
+// Do the reverb groups of a slot's mixed grid take the proven build for a call of n frames?  Every reverb of the slot proven, whole
+// tiles, and a last block that leaves their gains at rest.
+bool mixed_grid_proven(const oalsfx_batch* b, int slot, int n)
+{
+    return b->slow_count[slot] == 0 && b->fast_count[slot] > 0 && (n & 63) == 0 &&
+           (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 >= b->rest_tiles[slot] && !(debug_flags() & 0x200000);
 }
 
 // Ring-light effects and believed-steady reverbs of one slot in one grid (k_slot_mixed).
@@ -1283,13 +1293,14 @@ void launch_mixed_part(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     KernelCtx c = ctx;
     c.progress = nullptr; // an instance that turns out not to be steady falls back inside the grid
     // all of them proven, and a call whose last block leaves their gains at rest: the reverb groups take the FP build
-    const int n = ctx.frames;
-    const bool proven = b->slow_count[slot] == 0 && b->fast_count[slot] > 0 && (n & 63) == 0 &&
-                        (n - ((n - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE) / 64 >= b->rest_tiles[slot] && !(debug_flags() & 0x200000);
+    const bool proven = mixed_grid_proven(b, slot, ctx.frames);
     c.list_first = proven ? b->fast_first[slot] : -1;
     ScopedTiming timing(b, kTimedMixed, stream);
+    if (ctx.turn != nullptr) flags |= (debug_flags() & 0xFF) << 8; // (a chained launch: the hand-over's test switches)
+    int groups = 0;
     oalsfx_hip::launch_slot_mixed(c, slot, b->d_lists + b->steady_offset[slot], steady, b->d_lists + b->list_offset[slot][first_type], light,
-                                  seg, flags, proven, stream);
+                                  seg, flags, proven, stream, &groups);
+    b->launched_groups += groups;
 }
 
 // Number of consecutive slots from `slot` on that hold no reverb at all: such a run is one fused launch over every instance.
@@ -1410,9 +1421,15 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
         // kernel, a wavefront per instance walking its slots -- and the last slot one grid of steady-state reverbs.  Both take turns by
         // the same word per instance, the reverb slot's: launch after launch, whichever kernel it runs.  Whole tiles, no send filters,
         // and nothing to upload (a call that has a change to put in place goes in stream order, and ends the run).
-        const int last = b->slots - 1;
-        if (uploading || (frames & 63) != 0 || b->n_filtered > 0 || reverb_free_run(b, 0) != last || (debug_flags() & (0x8000000 | 0x40000))) return false;
-        if ((b->n + 3) / 4 < 1024 && frames < 256 && !(debug_flags() & 0x8000)) return false;
+        const int last = b->slots - 1, run = reverb_free_run(b, 0);
+        if (uploading || (frames & 63) != 0 || b->n_filtered > 0 || run < last || (debug_flags() & (0x8000000 | 0x40000))) return false;
+        // (batches that leave workgroup places free lose by it: 1024 instances 65.5 against 61.8 us per step, 2048: 77.5 against 70.0,
+        // 3072 level, 4096: 88.7 against 94.3, 6144: 134.8 against 162.2, 8192: 186.4 against 193.7 --
+        // profiles/r04g_two_launch_steps/config3_by_size.txt)
+        if ((b->n + 3) / 4 < 1024 && !(debug_flags() & 0x8000)) return false;
+        // (no reverb anywhere: the ring-light kernel's launch would be the whole step.  Measured slower chained -- 4096 x chorus -> flanger
+        // -> echo 47.4 against 44.7 us per step; see the single-slot case below -- unless the test switch asks for it)
+        if (run == b->slots) return (debug_flags() & 0x80) != 0;
         if (b->fast_count[last] + b->slow_count[last] != b->n || b->general_count[last] != 0) return false;
         KernelCtx ctx{};
         ctx.frames = frames;
@@ -1425,7 +1442,29 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     // profiles/r04e_round4_end/chained/instances_and_call_sizes.txt).
     if ((b->n + 3) / 4 < 1024 && frames < 256 && !(debug_flags() & 0x8000)) return false;
     const int steady = b->fast_count[0] + b->slow_count[0];
-    if (steady != b->n || b->general_count[0] != 0) return false;
+    if (b->general_count[0] != 0) return false;
+    if (steady != b->n) {
+        // A slot of ring-light effects, or of ring-light effects and proven reverbs (BASELINE configs[3]): the step is one grid as well --
+        // k_wave_effects with its segments, or k_slot_mixed on its proven build -- whose ring-light wavefronts take turns like the reverb
+        // groups do.  Whole tiles, no send filters, nothing to upload.
+        if (uploading || (frames & 63) != 0 || b->n_filtered > 0 || (debug_flags() & 0x40000)) return false;
+        KernelCtx ctx{};
+        ctx.frames = frames;
+        const SlotPlan pl = plan_slot(b, ctx, 0, frames, true);
+        if (pl.light + pl.steady != b->n || pl.reverbs != pl.steady) return false;
+        // Ring-light effects alone: measured slower chained than in stream order (4096 instances, 256-frame calls: chorus 18.9 against
+        // 15.1 us per step, dedicated 19.9 against 10.4, eight types in one slot 38 against 30.7 -- launches of 10 to 30 us are about what
+        // the host and the gate in front of each cost; profiles/r04h_mixed_grid_chained/ring_light_chained.txt).  With reverbs in the grid
+        // a launch is 45 us and more: BASELINE configs[3] 59.7 -> 51.5 us per step.  (0x80: the test switch that chains them anyway.)
+        if (pl.steady == 0) return (debug_flags() & 0x80) != 0;
+        // ... and what chaining gains there is the partly filled last round of the chip: the grid's workgroups differ in length by a factor
+        // of five, the next launch's are dispatched in order and wait in their places for turns that are far off, so a grid that fits
+        // the chip at once loses (4096 instances 42.8 against 36.0 us per step, 2048: 37.3 against 35.1), one of one to two rounds
+        // gains (6144: 41.4 against 44.9; 8192: 51.6 against 59.9), four full rounds are level (16 384: 108.2 against 107.3;
+        // profiles/r04h_mixed_grid_chained/config4_by_size.txt).
+        if ((b->n + 3) / 4 <= 1024 && !(debug_flags() & 0x8000)) return false;
+        return pl.mixed && mixed_grid_proven(b, 0, frames);
+    }
     if ((frames & 63) != 0) {
         // a call that ends in a partial tile chains when its step is one launch of the proven ragged builds (no general path inside, no
         // send-filter pre-pass in front)
@@ -1510,6 +1549,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
 {
     if (b->poisoned) return b->fail(b->fault_text);
     poll_exact(b);
+    b->launched_groups = 0;
     // what has changed since the last call: the host's part first (it decides what this call launches), the upload itself below, where
     // the call's launches go
     PendingUpload upload;
@@ -1643,7 +1683,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 {
                     ScopedTiming timing(b, kTimedWaveEffects, stream);
                     // (a chained step: in the order of the reverbs' grid -- its list names every instance once as well)
-                    const bool grid_order = chained && !(debug_flags() & 0x100);
+                    const bool grid_order = chained && s + run < b->slots && !(debug_flags() & 0x100);
                     const int* every = grid_order ? b->d_lists + b->steady_offset[b->slots - 1] : b->d_lists + b->list_offset[s][OALSFX_NULL];
                     oalsfx_hip::launch_wave_effects(ctx, s, run, every, b->n, nullptr,
                                                     run_flags | (chained ? ((debug_flags() & 3) | (grid_order ? 0 : 8)) << 8 : 0), stream);

@@ -157,7 +157,7 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const i
 // mono / stereo, whole tiles: the believed-steady reverbs and the ring-light effects of one slot in one grid (reverb.hip)
 // (`proven`: every listed reverb is proven steady and the call's blocks leave their gains at rest: the FP build of the reverb groups)
 void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
-                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream);
+                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream, int* groups = nullptr);
 // Send shelf filters of every instance (reference apply_filters, src/oalsfxpp.cpp:3101-3143): reads `src`, writes the direct
 // send's input to filtered[0] and slot s's to filtered[1 + s], each [instance][frames][channels] with stride ctx.src_stride.
 // `list` (may be nullptr: instances 0 .. instances - 1): the instances to look at (those among them without a filter are skipped)

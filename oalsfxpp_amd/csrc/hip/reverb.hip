@@ -2536,15 +2536,18 @@ __global__ __launch_bounds__(256, 4) void k_slot_mixed(KernelCtx ctx, int slot, 
         reverb_steady_group<CH, 4, false, true, true, true, RG, FP, !RG && !FP>(ctx, slot, steady_list, steady_count, flags, group, sh.steady);
         return;
     }
-    wfx::wave_block<CH>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
+    // (FP: the build that may be a chained launch -- ctx.turn: its ring-light wavefronts take turns like its reverb groups)
+    wfx::wave_block<CH, FP>(ctx, slot, 1, light_list, light_count, seg, flags, group - steady_groups, &sh.light[0][0], wfx::kLdsFloats);
 }
 
 void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, int steady_count, const int* light_list, int light_count,
-                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream)
+                       const WaveSegments& seg, int flags, bool proven, hipStream_t stream, int* groups)
 {
+    if (groups) *groups = 0;
     if (ctx.frames <= 0 || steady_count + light_count <= 0) return;
     const int light_blocks = seg.n > 0 ? seg.blocks() : (light_count + 3) / 4;
     const dim3 grid((steady_count + 3) / 4 + light_blocks), block(256);
+    if (groups) *groups = static_cast<int>(grid.x);
     const bool ragged = (ctx.frames & 63) != 0;
     if (proven && !ragged) {
         if (ctx.channels == 1) OALSFX_LAUNCH((k_slot_mixed<1, false, true>), grid, block, stream, ctx, slot, steady_list, steady_count, light_list, light_count, seg, flags);

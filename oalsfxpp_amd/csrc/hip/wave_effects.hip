@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256, CH == 8 ? 2 : 4) void k_wave_effects(KernelCtx
     if constexpr (CH == 1) OALSFX_EQUAL_PLACES(); // (the stereo build takes 128 registers as it is, and spilled with the statement)
 }
 
-// ctx.turn != nullptr: a launch of a run of chained launches (mono / stereo, no segments): the build whose wavefronts take turns.
+// ctx.turn != nullptr: a launch of a run of chained launches (mono / stereo): the build whose wavefronts take turns.
 void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const int* list, int count, const WaveSegments* seg, int flags,
                          hipStream_t stream)
 {
@@ -25,7 +25,7 @@ void launch_wave_effects(const KernelCtx& ctx, int slot, int slot_count, const i
     WaveSegments s{};
     if (seg && slot_count == 1) s = *seg;
     const dim3 grid(s.n > 0 ? s.blocks() : (count + 3) / 4), block(256);
-    if (ctx.turn != nullptr && s.n == 0 && ctx.channels <= 2) {
+    if (ctx.turn != nullptr && ctx.channels <= 2) {
         if (ctx.channels == 1) OALSFX_LAUNCH((k_wave_effects<1, true>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
         else OALSFX_LAUNCH((k_wave_effects<2, true>), grid, block, stream, ctx, slot, slot_count, list, count, s, flags);
         return;

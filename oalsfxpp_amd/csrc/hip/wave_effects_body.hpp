@@ -982,7 +982,7 @@ __device__ __forceinline__ void wave_slots(const KernelCtx& ctx, int slot, int s
 // The ring-light part of a grid: workgroup `block` of it, four wavefronts.  With segments (a single slot), the blocks follow
 // the slot's type-sorted list segment by segment, so that a workgroup holds one effect type; without, wavefront w takes
 // list[w].
-// CHN: a launch of a run of chained launches (batch.cpp; no segments): the workgroup counts itself in, and a wavefront takes its
+// CHN: a launch of a run of chained launches (batch.cpp): the workgroup counts itself in, and a wavefront takes its
 // instance when the launch before is through with it and hands it on behind its last store (common.hpp: turn_take, turn_hand_on).
 template <int CH, bool CHN = false>
 __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int slot_count, const int* __restrict__ list, int count,
@@ -1014,7 +1014,10 @@ __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int s
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     unsigned cu_before = 0;
     const size_t word = static_cast<size_t>(inst) * ctx.slots + ctx.turn_slot;
-    if (CHN && !turn_take(ctx, word, lane, flags >> 8, cu_before)) return; // (its turn never came: the instance is left as it is)
+    const bool mine = !CHN || turn_take(ctx, word, lane, flags >> 8, cu_before);
+    // (its turn never came: the instance is left as it is -- and in a cooperative workgroup, whose wavefronts meet at barriers, all four are)
+    if (CHN && group.coop) { if (__syncthreads_or(mine ? 0 : 1)) return; }
+    else if (!mine) return;
     wave_slots<CH>(ctx, slot, slot_count, inst, flags, lds_group + wib * lds_stride, lane, group);
     if (CHN) turn_hand_on(ctx, word, lane, cu_before);
 }

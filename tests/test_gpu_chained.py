@@ -848,3 +848,88 @@ def test_every_instance_of_configs_2_through_consecutive_steps_of_two_launches()
         for s in army.shadows[::97]:
             d = s.compare_state()
             assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
+
+
+# ---- single grids of ring-light effects, alone or beside proven reverbs, as chained launches (round 4) ----
+
+def _a_run_of_one_mixed_grid(n, fmt, seed, script, expect_chained, reverbs=True, slots=1, workload=None):
+    """One slot whose instances hold any of the eleven non-null types (reverbs: EFX presets, so that every one is steady), or `slots` slots
+    of ring-light types only; calls in a row without synchronisation, followed instances against the oracle buffer by buffer, then
+    states and delay lines."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect, setup
+    rng = random.Random(seed)
+    with Batch(n, fmt, 48000, slots) as b:
+        if workload:
+            setup(b, workload)
+        else:
+            for s in range(slots):
+                effects = []
+                for i in range(n):
+                    t = 1 + (i + s) % 11 if reverbs else LIGHT_TYPES[(i + 3 * s) % len(LIGHT_TYPES)]
+                    effects.append(preset_effect(rng.randrange(113), t) if t in (desc.REVERB, desc.EAX_REVERB) else random_effect(rng, t))
+                b.set_effect(s, effects)
+            b.apply_changes()
+        picks = sorted(set(list(range(min(n, 12))) + [n // 2, n - 2, n - 1] + list(range(5, n, max(1, n // 11)))))
+        shadows = {i: OracleShadow(b, i) for i in picks}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+        for _ in range(4):
+            b.mix(warm)                    # through the reverbs' start-up cross-fade; proven
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        before = b.chained_calls
+        h0, d0 = b.chain_started()
+        run_device_calls(b, script, shadows, seed, replicas=False)
+        assert b.chained_calls - before >= expect_chained, (before, b.chained_calls)
+        h1, d1 = b.chain_started()
+        assert h1 == d1, f"host {h1} and device {d1} disagree"
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
+
+
+@pytest.mark.parametrize("fmt", [desc.FMT_MONO, desc.FMT_STEREO])
+def test_a_slot_of_eleven_types_chains(fmt):
+    """BASELINE configs[3]'s shape: ring-light effects and reverbs in one slot, one grid (k_slot_mixed on its proven build) whose
+    cooperative workgroups, lone wavefronts and reverb groups all take turns.  88 instances: whole cooperative workgroups and leftovers
+    of every type."""
+    _a_run_of_one_mixed_grid(88, fmt, 51000, [256] * 24 + [64, 128, 512, 2048, 256, 256], 30)
+
+
+def test_a_slot_of_eleven_types_chains_with_the_same_cu_path_taken_by_every_wavefront():
+    _with_debug_flags(1, lambda: _a_run_of_one_mixed_grid(88, desc.FMT_STEREO, 52000, [256] * 24, 24))
+
+
+def test_configs_3_chains_at_full_size():
+    """BASELINE configs[3] itself: 8192 instances, type 1 + i % 11, random properties."""
+    _a_run_of_one_mixed_grid(8192, desc.FMT_STEREO, 53000, [256] * 30, 0, workload="config4")
+
+
+CHAIN_RING_LIGHT = 0x80   # batches without any reverb stay in stream order in the product (measured slower chained); the hand-over is tested all the same
+
+
+@pytest.mark.parametrize("slots", [1, 3])
+def test_ring_light_effects_alone_chain(slots):
+    """No reverb anywhere: the ring-light kernel's launch is the whole step (one slot: its grid of type segments with cooperative
+    workgroups; several: one wavefront per instance walking the slots)."""
+    _with_debug_flags(CHAIN_RING_LIGHT, lambda: _a_run_of_one_mixed_grid(90, desc.FMT_STEREO, 54000 + slots, [256] * 24 + [64, 128, 512, 2048, 256, 256],
+                                                                         30, reverbs=False, slots=slots))
+
+
+def test_ring_light_effects_alone_chain_at_full_size():
+    _with_debug_flags(CHAIN_RING_LIGHT, lambda: _a_run_of_one_mixed_grid(4096, desc.FMT_STEREO, 55000, [256] * 40, 40, reverbs=False))
+
+
+def test_ring_light_effects_alone_stay_in_stream_order():
+    with Batch(90, desc.FMT_STEREO, 48000, 1) as b:
+        import torch
+        b.set_effect_type(0, desc.CHORUS)
+        b.apply_changes()
+        x = torch.zeros(90 * 256 * 2, device="cuda")
+        y = torch.empty_like(x)
+        for _ in range(8):
+            b.mix_device(256, x.data_ptr(), y.data_ptr())
+        b.synchronize()
+        assert b.chained_calls == 0
