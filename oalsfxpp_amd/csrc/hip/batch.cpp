@@ -1627,7 +1627,11 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
     // (a chained step of two kernels: workgroups of one size, so that either kernel's fit the places the other's give up -- common.hpp)
     struct EqualPlaces {
         bool on;
-        explicit EqualPlaces(bool o) : on(o) { if (on) oalsfx_hip::set_lds_per_workgroup(40960); }
+        explicit EqualPlaces(bool o) : on(o)
+        {
+            static const int bytes = std::getenv("OALSFX_EQUAL_LDS") ? std::atoi(std::getenv("OALSFX_EQUAL_LDS")) : 40960; // (experiments)
+            if (on) oalsfx_hip::set_lds_per_workgroup(bytes);
+        }
         ~EqualPlaces() { if (on) oalsfx_hip::set_lds_per_workgroup(0); }
     } equal_places(chained && b->slots > 1 && !(debug_flags() & 0x1000));
     // Api::mix chunking (reference src/oalsfxpp.cpp:3818-3826)

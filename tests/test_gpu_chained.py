@@ -933,3 +933,68 @@ def test_ring_light_effects_alone_stay_in_stream_order():
             b.mix_device(256, x.data_ptr(), y.data_ptr())
         b.synchronize()
         assert b.chained_calls == 0
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_SEEDS", "6")))))
+def test_random_runs_of_the_other_shapes(seed):
+    """Random batches of the shapes whose steps chain since round 4 -- reverb-free slots in front of a reverb slot (two launches per step),
+    one slot of ring-light effects and reverbs (the mixed grid), ring-light effects alone (test switch) -- with 6 to 128 instances (few
+    workgroups, whose places shift from launch to launch: where the same-CU path and the gates are exercised), random call sizes, ragged
+    calls and effect changes in between (which go in stream order and end a run).  Every output buffer of the followed instances, then
+    states and delay lines, and the gates' count on host and device."""
+    import random
+    from oalsfxpp_amd.workloads import random_effect
+    rng = random.Random(77000 + seed)
+    fmt = rng.choice([desc.FMT_MONO, desc.FMT_STEREO])
+    n = rng.choice([6, 8, 24, 30, 70, 72, 127, 128])
+    shape = rng.choice(["two launches", "two launches", "mixed grid", "mixed grid", "ring-light"])
+    slots = rng.choice([2, 3, 4]) if shape == "two launches" else rng.choice([1, 1, 3]) if shape == "ring-light" else 1
+
+    def an_effect(slot, i):
+        if shape == "two launches" and slot == slots - 1:
+            return preset_effect(rng.randrange(113), rng.choice([desc.REVERB, desc.EAX_REVERB]))
+        if shape == "mixed grid" and (i % 3 == 0 or rng.random() < 0.2):
+            return preset_effect(rng.randrange(113), rng.choice([desc.REVERB, desc.EAX_REVERB]))
+        return random_effect(rng, LIGHT_TYPES[rng.randrange(len(LIGHT_TYPES))])
+
+    def body():
+        with Batch(n, fmt, 48000, slots) as b:
+            for s in range(slots):
+                b.set_effect(s, [an_effect(s, i) for i in range(n)])
+            b.apply_changes()
+            followed = sorted(rng.sample(range(n), min(n, 12)))
+            shadows = {i: OracleShadow(b, i) for i in followed}
+            for s in shadows.values():
+                s.sync()
+            warm = np.zeros((n, 256, b.channels), dtype=np.float32)
+            for _ in range(4):
+                b.mix(warm)
+                for s in shadows.values():
+                    s.oracle.mix(warm[0])
+
+            def change(slot, instances):
+                def op():
+                    for i in instances:
+                        b.set_effect(slot, an_effect(slot, i), first=i, count=1)
+                    b.apply_changes()
+                return op
+
+            script = []
+            for _ in range(36):
+                r = rng.random()
+                if r < 0.74:
+                    script.append(rng.choice([64, 128, 256, 256, 256, 512, 1024, 2048]))
+                elif r < 0.82:
+                    script.append(rng.choice([1, 63, 100, 300]))
+                else:
+                    script.append(change(rng.randrange(slots), [rng.choice(followed) if rng.random() < 0.7 else rng.randrange(n) for _ in range(rng.choice([1, 1, 2, 5]))]))
+            script += [256, 256, 256]
+            run_device_calls(b, script, shadows, 78000 + 100 * seed, replicas=False)
+            # (a batch may legitimately chain nothing: a reverb that stays outside the steady-state builds, a change before every call)
+            h1, d1 = b.chain_started()
+            assert h1 == d1, f"seed {seed} ({shape}, {slots} slots, {n} instances): host {h1} and device {d1} disagree"
+            for i, s in shadows.items():
+                d = s.compare_state()
+                assert not d, f"seed {seed} ({shape}, {slots} slots, {n} instances), instance {i}: " + "; ".join(d[:4])
+
+    _with_debug_flags(CHAIN_RING_LIGHT, body)
