@@ -1270,7 +1270,7 @@ void launch_wave_group(oalsfx_batch* b, const KernelCtx& ctx, int slot, int flag
     const int count = wave_segments(b, slot, first_type, seg);
     if (count == 0) return;
     ScopedTiming timing(b, kTimedWaveEffects, stream);
-    if (ctx.turn != nullptr) { flags |= (debug_flags() & 3) << 8; b->launched_groups += seg.blocks(); } // (a chained launch: test switches, the gate's count)
+    if (ctx.turn != nullptr) { flags |= (debug_flags() & 7) << 8; b->launched_groups += seg.blocks(); } // (a chained launch: test switches, the gate's count)
     oalsfx_hip::launch_wave_effects(ctx, slot, 1, b->d_lists + b->list_offset[slot][first_type], count, &seg, flags, stream);
 }
 
@@ -1690,7 +1690,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                     const bool grid_order = chained && s + run < b->slots && !(debug_flags() & 0x100);
                     const int* every = grid_order ? b->d_lists + b->steady_offset[b->slots - 1] : b->d_lists + b->list_offset[s][OALSFX_NULL];
                     oalsfx_hip::launch_wave_effects(ctx, s, run, every, b->n, nullptr,
-                                                    run_flags | (chained ? ((debug_flags() & 3) | (grid_order ? 0 : 8)) << 8 : 0), stream);
+                                                    run_flags | (chained ? ((debug_flags() & 7) | (grid_order ? 0 : 8)) << 8 : 0), stream);
                 }
                 if (chained) b->launched_groups = (b->n + 3) / 4;
                 s += run - 1;

@@ -497,6 +497,15 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     }
                 }
             }
+            if (!(flags & kFirst) && ctx.mixbuf != nullptr) {
+                // (a step of two launches: the mix of the slots in front, which the ring-light kernel's launch is writing -- a dword of every line)
+                const unsigned* mb = reinterpret_cast<const unsigned*>(ctx.mixbuf + static_cast<size_t>(inst) * nch * OALSFX_MAX_CHUNK);
+                for (int c = 0; c < nch; ++c) {
+                    unsigned a;
+                    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(mb + c * OALSFX_MAX_CHUNK + 32 * lane) : "memory");
+                    junk ^= a;
+                }
+            }
             if (junk == 0x7E57AB1Eu && ctx.timeline) ctx.timeline[0] = junk; // (keeps the loads)
         }
         int lost = 0;

@@ -1014,6 +1014,30 @@ __device__ __forceinline__ void wave_block(const KernelCtx& ctx, int slot, int s
     const int inst = __builtin_amdgcn_readfirstlane(list[w]);
     unsigned cu_before = 0;
     const size_t word = static_cast<size_t>(inst) * ctx.slots + ctx.turn_slot;
+    if (CHN && ((flags >> 8) & 4) && ctx.turn != nullptr && ctx.turn_wait != 0u) {
+        // Test switch 4 (tests/test_gpu_chained.py): the wavefront reads its instance's state and the first lines of its mix buffer *before*
+        // its turn has come -- what the hand-over forbids -- so that this CU's L1 holds them as they were while the launch before is
+        // still at work on them: without the acquire behind the wait (switch 2) the run must come out wrong, with it (1) right.
+        unsigned junk = 0;
+        for (int sl = slot; sl < slot + slot_count; ++sl) {
+            const unsigned* st = reinterpret_cast<const unsigned*>(ctx.state + static_cast<size_t>(inst) * ctx.slots + sl);
+#pragma unroll
+            for (int k = 0; k < static_cast<int>(sizeof(SlotStateLines) / 256); ++k) {
+                unsigned a;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(st + 64 * k + lane) : "memory"); // (the wait inside: the compiler does not know the load is in flight)
+                junk ^= a;
+            }
+        }
+        if (ctx.mixbuf != nullptr) {
+            const unsigned* mb = reinterpret_cast<const unsigned*>(ctx.mixbuf + static_cast<size_t>(inst) * ctx.channels * OALSFX_MAX_CHUNK);
+            for (int c = 0; c < ctx.channels; ++c) {
+                unsigned a;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(mb + c * OALSFX_MAX_CHUNK + 32 * lane) : "memory");
+                junk ^= a;
+            }
+        }
+        if (junk == 0x7E57AB1Eu && ctx.timeline) ctx.timeline[0] = junk; // (keeps the loads)
+    }
     const bool mine = !CHN || turn_take(ctx, word, lane, flags >> 8, cu_before);
     // (its turn never came: the instance is left as it is -- and in a cooperative workgroup, whose wavefronts meet at barriers, all four are)
     if (CHN && group.coop) { if (__syncthreads_or(mine ? 0 : 1)) return; }

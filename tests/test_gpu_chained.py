@@ -787,6 +787,17 @@ def test_steps_of_two_launches_with_the_same_cu_path_taken_by_every_wavefront(n)
     _with_debug_flags(1, lambda: _a_run_of_steps_of_two_launches(n, desc.FMT_STEREO, 43000, [256] * 24, 24))
 
 
+def test_steps_of_two_launches_lines_read_before_the_turn_are_caught_without_the_acquire_and_cured_by_it():
+    """The ring-light kernel's negative control: debug flag 4 makes every wavefront of either kernel read its instance's
+    lines -- state, hot record, all-pass rings, the mix buffer's first lines -- before its turn has come.  70 instances (few workgroups,
+    launches overlap for most of their length): without the acquire behind the wait the run must come out wrong, with it right."""
+    from oalsfxpp_amd.api import BatchError
+    with pytest.raises((AssertionError, BatchError)):
+        _with_debug_flags(4 | 2, lambda: _a_run_of_steps_of_two_launches(70, desc.FMT_STEREO, 46000, [256] * 24, 24))
+    _with_debug_flags(4 | 1, lambda: _a_run_of_steps_of_two_launches(70, desc.FMT_STEREO, 46000, [256] * 24, 24))
+    _a_run_of_steps_of_two_launches(70, desc.FMT_STEREO, 46000, [256] * 24, 24)
+
+
 def test_a_run_of_steps_of_two_launches_ends_for_a_change_and_starts_again():
     """A call that has a parameter change to put in place goes in stream order (the two-launch step does not take uploads into the run),
     and the calls behind it chain again."""
@@ -900,6 +911,13 @@ def test_a_slot_of_eleven_types_chains(fmt):
 
 def test_a_slot_of_eleven_types_chains_with_the_same_cu_path_taken_by_every_wavefront():
     _with_debug_flags(1, lambda: _a_run_of_one_mixed_grid(88, desc.FMT_STEREO, 52000, [256] * 24, 24))
+
+
+def test_a_slot_of_eleven_types_lines_read_before_the_turn_are_caught_without_the_acquire_and_cured_by_it():
+    from oalsfxpp_amd.api import BatchError
+    with pytest.raises((AssertionError, BatchError)):
+        _with_debug_flags(4 | 2, lambda: _a_run_of_one_mixed_grid(88, desc.FMT_STEREO, 57000, [256] * 24, 24))
+    _with_debug_flags(4 | 1, lambda: _a_run_of_one_mixed_grid(88, desc.FMT_STEREO, 57000, [256] * 24, 24))
 
 
 def test_configs_3_chains_at_full_size():
