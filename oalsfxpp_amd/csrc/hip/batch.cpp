@@ -1053,7 +1053,7 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // order: as before round 4), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
 // of tests/test_gpu_chained.py: it must fail), 0x40000 no chained steps of two launches (batches of several slots in stream order, as
-// before round 4), 0x100 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
+// before round 4), 0x10 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
 // 0x80 batches without any reverb chain their calls too (tests of the ring-light kernel's hand-over; measured slower: chain_eligible),
 // 0x1000 a chained step's two kernels with the workgroup sizes they declare (experiment: the places one kernel's workgroups give up
 // do not fit the other's).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
@@ -1687,7 +1687,7 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
                 {
                     ScopedTiming timing(b, kTimedWaveEffects, stream);
                     // (a chained step: in the order of the reverbs' grid -- its list names every instance once as well)
-                    const bool grid_order = chained && s + run < b->slots && !(debug_flags() & 0x100);
+                    const bool grid_order = chained && s + run < b->slots && !(debug_flags() & 0x10);
                     const int* every = grid_order ? b->d_lists + b->steady_offset[b->slots - 1] : b->d_lists + b->list_offset[s][OALSFX_NULL];
                     oalsfx_hip::launch_wave_effects(ctx, s, run, every, b->n, nullptr,
                                                     run_flags | (chained ? ((debug_flags() & 7) | (grid_order ? 0 : 8)) << 8 : 0), stream);
