@@ -1457,10 +1457,9 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
         // the host and the gate in front of each cost; profiles/r04h_mixed_grid_chained/ring_light_chained.txt).  With reverbs in the grid
         // a launch is 45 us and more: BASELINE configs[3] 59.7 -> 51.5 us per step.  (0x80: the test switch that chains them anyway.)
         if (pl.steady == 0) return (debug_flags() & 0x80) != 0;
-        // ... and what chaining gains there is the partly filled last round of the chip: the grid's workgroups differ in length by a factor
-        // of five, the next launch's are dispatched in order and wait in their places for turns that are far off, so a grid that fits
-        // the chip at once loses (4096 instances 42.8 against 36.0 us per step, 2048: 37.3 against 35.1), one of one to two rounds
-        // gains (6144: 41.4 against 44.9; 8192: 51.6 against 59.9), four full rounds are level (16 384: 108.2 against 107.3;
+        // ... and what chaining gains there is the partly filled last round of the chip: a grid that fits the chip at once loses (4096
+        // instances 42.8 against 36.0 us per step, 2048: 37.3 against 35.1 -- whatever the order of its workgroups), one of one to two
+        // rounds gains (6144: 41.4 against 44.9; 8192: 51.6 against 59.9), four full rounds are level (16 384: 108.2 against 107.3;
         // profiles/r04h_mixed_grid_chained/config4_by_size.txt).
         if ((b->n + 3) / 4 <= 1024 && !(debug_flags() & 0x8000)) return false;
         return pl.mixed && mixed_grid_proven(b, 0, frames);
