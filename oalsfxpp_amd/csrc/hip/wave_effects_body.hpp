@@ -270,6 +270,9 @@ struct DedicatedW {
     __device__ void finish(const Inst&) {}
 };
 
+#ifndef OALSFX_MODDELAY_AHEAD
+#define OALSFX_MODDELAY_AHEAD 1 // 0: A/B builds without the request one tile ahead
+#endif
 // chorus / flanger (reference src/oalsfxpp.cpp:4113-4276, 5384-5547): buf[o] = in; t = buf[o - d] * feedback; buf[o] += t; out = t
 struct ModDelayW {
     // (The LFO's phase, `offset % lfo_range`, is an integer division by a run-time divisor per lane, twice per tile.  Round 4 carried
@@ -278,7 +281,19 @@ struct ModDelayW {
     // (profiles/r04c_instruction_diet/lfo_phase_by_additions.txt).  The tile is a chain of latencies behind the dependent ring load;
     // the division was never on it.  Taken out again.)
     int offset;
-    __device__ void init(const Inst& I) { offset = I.ss->u.moddelay.offset; }
+    // Round 4: the ring values of the next tile, requested one tile ahead when every lane's delay is at least two tiles long (the chorus:
+    // 16 ms +- its depth; what the next tile reads then lies before this tile's writes) -- the tile is the latency of that dependent load
+    // and little else, so the next tile's is put behind this tile's work, as the echo's taps are.
+    float v_next[2];
+    bool have_next, may_ask; // may_ask: the LFO's lowest delay is two tiles long (a flanger's is not: it would pay for the second delay per tile and never ask)
+    __device__ void init(const Inst& I)
+    {
+        const auto& p = I.sp->u.moddelay;
+        offset = I.ss->u.moddelay.offset;
+        may_ask = p.delay - static_cast<int>(fabsf(p.depth)) - 1 >= 128;
+        have_next = false;
+        v_next[0] = v_next[1] = 0.0F;
+    }
     template <class P> __device__ static int lfo_delay(const P& p, int phase)
     {
         if (p.waveform == 1) return static_cast<int>((1.0F - fabsf(2.0F - (p.lfo_scale * phase))) * p.depth) + p.delay;
@@ -299,14 +314,35 @@ struct ModDelayW {
         int d[2];
         bool inside[2];
         float v[2];
+        if (have_next) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
-            const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
-            d[k] = lfo_delay(p, phase);
-            inside[k] = d[k] > 0 && lane - d[k] >= 0; // written by an earlier lane of this tile
-            v[k] = in;
-            if (lane < L && d[k] != 0 && !inside[k]) v[k] = buf[static_cast<unsigned>(o - d[k]) & mask];
+            for (int k = 0; k < 2; ++k) {
+                d[k] = 128;        // (at least: no source inside the tile, and nothing else asks)
+                inside[k] = false;
+                v[k] = lane < L ? v_next[k] : in;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const GlobalFloat* buf = I.ring + (k ? p.ring_len : 0);
+                const int phase = (k ? o + p.lfo_disp : o) % p.lfo_range;
+                d[k] = lfo_delay(p, phase);
+                inside[k] = d[k] > 0 && lane - d[k] >= 0; // written by an earlier lane of this tile
+                v[k] = in;
+                if (lane < L && d[k] != 0 && !inside[k]) v[k] = buf[static_cast<unsigned>(o - d[k]) & mask];
+            }
+        }
+        // the next tile's sources, while this tile is worked on (a call's last tile asks for nothing: L < 64, or one request too many)
+        have_next = false;
+        if (OALSFX_MODDELAY_AHEAD && may_ask && L == 64) {
+            int dn[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) dn[k] = lfo_delay(p, (k ? o + 64 + p.lfo_disp : o + 64) % p.lfo_range);
+            have_next = __ballot(dn[0] < 128 || dn[1] < 128) == 0ULL;
+            if (have_next) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) v_next[k] = (I.ring + (k ? p.ring_len : 0))[static_cast<unsigned>(o + 64 - dn[k]) & mask];
+            }
         }
         // both sides walk the tile together: a side with a short delay needs many rounds (64 / delay), each one a ballot and a
         // lane permute whose latencies the other side's round hides
