@@ -1572,6 +1572,8 @@ bool mix_device(oalsfx_batch* b, int frames, const float* src, float* dst, hipSt
         // stream's start three times over.  Two it stays; OALSFX_DEBUG_FLAGS 0x10000: three.
         // profiles/r04c_instruction_diet/chain_depth_uniform.txt)
         depth = (populated > 1 || b->slow_count[rs] > 0 || upload.st || (debug_flags() & 0x10000)) ? kChainDepth : std::min(2, kChainDepth);
+        static const int forced_depth = std::getenv("OALSFX_CHAIN_DEPTH") ? std::atoi(std::getenv("OALSFX_CHAIN_DEPTH")) : 0; // (experiments)
+        if (forced_depth >= 2 && forced_depth <= kChainDepth) depth = forced_depth;
     }
     if (!chained && !launch_params(b, upload, b->stream, stream)) return false;
     if (!ensure_mixbuf(b)) return false;
