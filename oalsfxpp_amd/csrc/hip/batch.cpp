@@ -125,7 +125,7 @@ struct oalsfx_batch {
     unsigned* d_inst_epoch = nullptr;             // [n]
     unsigned* d_exact = nullptr;                  // [n*slots] "settled and at rest" as the reverb kernels left it
     unsigned* h_exact = nullptr;                  // pinned copy of d_exact, filled by the read-back
-    char fault_text[200] = {};
+    char fault_text[400] = {};
     long long host_prepare_ns = 0, host_stage_wait_ns = 0, host_derive_ns = 0, host_lists_ns = 0; // OALSFX_HOST_PROFILE: where the host's time inside mix_device goes
     unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
     unsigned* d_fault = nullptr;                  // device address of h_fault
@@ -1333,7 +1333,7 @@ bool check_fault(oalsfx_batch* b)
     if (!b->h_fault || *b->h_fault == 0) return true;
     const unsigned f = *b->h_fault;
     if (f >= oalsfx_hip::kFaultTurn) {
-        std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady).",
+        std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady; gates alone: something ran the queues' kernels one at a time and out of order -- OALSFX_DEBUG_FLAGS=0x400 gives plain stream order).",
                       f, (f / oalsfx_hip::kFaultTurn) & 0xFFFu, f / oalsfx_hip::kFaultGate, f & 0xFFFu);
         // (the instances concerned were left alone, and so were the launches behind them in the run: the batch's state is a buffer short
         // there.  No further call pretends otherwise.)
@@ -1394,8 +1394,25 @@ bool chain_join(oalsfx_batch* b)
 // and a step that is exactly one steady-state launch.  (Any number of workgroups: the gate in front of a launch sees to it that all but
 // a few workgroups of the launch before have started, however many rounds of the chip that launch takes -- 32 768 instances, eight
 // rounds: 380 -> 360 us per step.)
+// Is this process run under a tool that collects hardware counters per kernel (rocprofv3 --pmc, or a counter file)?  Such a tool runs
+// one kernel at a time, and not in the order the queues were fed: the gate in front of a chained launch then waits for a launch the tool
+// holds back until the gate has finished -- every gate counts out (1.3 s each; measured: bench.py under `rocprofv3 --pmc SQ_WAVES`
+// failed with "a chained launch gave up waiting (... 31 gates ...)", profiles/r04k_under_the_profiler/).  Kernels that cannot overlap
+// gain nothing from chaining anyway: stream order there.  (Tracing -- --kernel-trace, --stats -- does not serialise and chains as usual.)
+bool kernels_serialised_by_a_tool()
+{
+    static const bool yes = [] {
+        const char* on = std::getenv("ROCPROF_COUNTER_COLLECTION");   // rocprofv3 --pmc / -i: "1"
+        const char* which = std::getenv("ROCPROF_COUNTERS");          // ... and the counters asked for
+        const char* v1 = std::getenv("ROCP_METRICS");                 // rocprof (v1) with an input file
+        return (on && std::atoi(on) != 0) || (which && *which) || (v1 && *v1);
+    }();
+    return yes;
+}
+
 bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream, bool uploading)
 {
+    if (kernels_serialised_by_a_tool()) return false;
     if (b->chain_open && b->chain_dsts.size() >= 256) {
         // (a caller that hands in a fresh output buffer with every call: the list of a run's output buffers starts over with a new run)
         const char* lo = reinterpret_cast<const char*>(dst);

@@ -1,5 +1,5 @@
 """Chained launches: step time of the headline loop with consecutive calls overlapping (default) and in plain stream order
-(OALSFX_DEBUG=0x400), instances / frames from the command line.  python3 scripts/chain_probe.py [instances] [frames] [calls] [config3]"""
+(OALSFX_DEBUG=0x400), instances / frames from the command line.  python3 scripts/chain_probe.py [instances] [frames] [calls] [config3 | config4]"""
 import sys, time
 sys.path.insert(0, ".")
 import torch
@@ -8,10 +8,14 @@ from oalsfxpp_amd.api import Batch
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+mixed = len(sys.argv) > 4 and sys.argv[4] == "config4"   # BASELINE configs[3]: type 1 + i % 11, random properties: one mixed grid per step
 chain4 = len(sys.argv) > 4 and sys.argv[4] == "config3"  # BASELINE configs[2]: chorus -> flanger -> echo -> EAX reverb, a step of two launches
 b = Batch(n, desc.FMT_STEREO, 48000, 4 if chain4 else 1)
 if chain4:
     for s, t in enumerate((desc.CHORUS, desc.FLANGER, desc.ECHO, desc.EAX_REVERB)): b.set_effect_type(s, t)
+elif mixed:
+    from oalsfxpp_amd.workloads import setup
+    setup(b, "config4")
 else:
     b.set_effect_type(0, desc.EAX_REVERB)
 b.apply_changes()

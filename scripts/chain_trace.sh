@@ -9,7 +9,7 @@ import csv, glob, os
 O = os.environ["O"]
 f = glob.glob(O + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if "steady" in r["Kernel_Name"] or "gate" in r["Kernel_Name"] or "wave_effects" in r["Kernel_Name"]]
+rows = [r for r in rows if "steady" in r["Kernel_Name"] or "gate" in r["Kernel_Name"] or "wave_effects" in r["Kernel_Name"] or "slot_mixed" in r["Kernel_Name"]]
 tail = rows[-40:]
 t0 = int(tail[0]["Start_Timestamp"])
 with open(O + "/timeline.txt", "w") as out:
@@ -19,7 +19,7 @@ with open(O + "/timeline.txt", "w") as out:
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
         out.write(f"{s:9.1f} {e:9.1f} {e - s:7.1f} {'' if ps is None else f'{s - ps:7.1f}':>7} {'' if pe is None else f'{e - pe:7.1f}':>7}  q{r.get('Queue_Id', '?')}  {r['Kernel_Name'][:60]}\n")
         ps, pe = s, e
-    ends = [int(r["End_Timestamp"]) for r in rows if "steady" in r["Kernel_Name"]][-200:]
+    ends = [int(r["End_Timestamp"]) for r in rows if "steady" in r["Kernel_Name"] or "slot_mixed" in r["Kernel_Name"]][-200:]
     out.write(f"end-to-end interval over the last {len(ends)} reverb launches: {(ends[-1] - ends[0]) / 1e3 / (len(ends) - 1):.2f} us\n")
 print(open(O + "/timeline.txt").read())
 os.remove(f)

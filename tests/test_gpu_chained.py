@@ -1016,3 +1016,24 @@ def test_random_runs_of_the_other_shapes(seed):
                 assert not d, f"seed {seed} ({shape}, {slots} slots, {n} instances), instance {i}: " + "; ".join(d[:4])
 
     _with_debug_flags(CHAIN_RING_LIGHT, body)
+
+
+def test_calls_stay_in_stream_order_under_a_tool_that_collects_counters():
+    """rocprofv3 --pmc runs one kernel at a time and not in the order the queues were fed: the gates of chained launches count out
+    (bench.py under `rocprofv3 --pmc SQ_WAVES` failed that way).  The library sees the tool's environment and leaves every call in
+    stream order.  (A process of its own: the check is made once.)"""
+    import os, subprocess, sys
+    code = ("import sys; sys.path.insert(0, '.'); import torch; from oalsfxpp_amd import desc; from oalsfxpp_amd.api import Batch\n"
+            "b = Batch(4096, desc.FMT_STEREO, 48000, 1); b.set_effect_type(0, desc.EAX_REVERB); b.apply_changes()\n"
+            "x = torch.zeros(4096 * 256 * 2, device='cuda'); y = torch.empty_like(x)\n"
+            "for _ in range(6): b.mix_device(256, x.data_ptr(), y.data_ptr()); b.synchronize()\n"
+            "for _ in range(12): b.mix_device(256, x.data_ptr(), y.data_ptr())\n"
+            "b.synchronize(); print('chained', b.chained_calls)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra, chains in (({"ROCPROF_COUNTER_COLLECTION": "1", "ROCPROF_COUNTERS": "pmc: SQ_WAVES"}, False), ({}, True)):
+        env = dict(os.environ, **env_extra)
+        env.pop("OALSFX_DEBUG_FLAGS", None)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        chained = int(out.stdout.split("chained")[1])
+        assert (chained >= 12) if chains else (chained == 0), (env_extra, out.stdout, out.stderr[-500:])
