@@ -346,6 +346,8 @@ def main():
                                                            "the `config5` object; always on when --gpus > 1")
     ap.add_argument("--host-io", type=int, default=10, metavar="K",
                     help="after the timed region, also time K steps through the host-pointer entry points (PCIe both ways)")
+    ap.add_argument("--no-other-configs", action="store_true", help="leave out the `other_configs` object (configs[2] and configs[3], 100 steps each, "
+                                                                    "in single-GPU runs of the default workload)")
     ap.add_argument("--no-config5", action="store_true", help="multi-GPU runs: leave the `config5` object out (rehearsals on one GPU)")
     ap.add_argument("--in-process", action="store_true", help="time the C ABI's group object instead (oalsfx_group_*: one process, a batch and a host "
                                                               "thread per device); the driver's contract is the default, one process per GPU")
@@ -584,6 +586,11 @@ def main():
     del src, dst
     torch.cuda.empty_cache()
 
+    if world == 1 and workload == "config2" and not config5_main and not args.preset_mix and args.instances == 0 and not args.no_other_configs and not args.in_process:
+        # BASELINE.json's other single-GPU configurations in the same run, briefly (the headline stays configs[1]): configs[2], the 4-slot
+        # chain, and configs[3], eleven effect types in one slot -- whole-step figures like `value`, inputs resident in HBM
+        result["other_configs"] = {name: other_config_leg(name, 100, sharding, backend) for name in ("config3", "config4")}   # (100 steps whatever --steps says: a report beside the headline)
+
     if (args.config5 or distributed) and not config5_main and not args.no_config5:
         result["config5"] = config5_leg(rank, world, local_rank, min(args.steps, 100), sharding, backend)
 
@@ -656,6 +663,31 @@ def host_io_leg(batch, n, steps):
     return out
 
 
+def other_config_leg(name, steps, sharding, backend):
+    """`steps` steps of another BASELINE configuration (bench.py --workload <name> is the full report), timed like the main region."""
+    from oalsfxpp_amd import desc, workloads
+    from oalsfxpp_amd.api import Batch
+    n = {"config3": 4096, "config4": 8192}[name]
+    batch = Batch(n, desc.FMT_STEREO, 48000, workloads.effect_count(name), device_id=0)
+    workloads.setup(batch, name)
+    n_in = 4
+    src, dst = resident_inputs(batch, n, 0, n_in)
+    for k in range(8):   # (through the reverbs' start-up cross-fade, call by call: the device's report of what has settled is read back between calls)
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+        batch.synchronize()
+    for k in range(40):
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+    before = batch.chained_calls
+    elapsed = timed_region(batch, src, dst, n_in, 0, steps, sharding, backend)
+    out = {"workload": WORKLOADS[name].format(n=n), "value": round(n * FRAMES * steps / elapsed / 1e6, 3), "unit": "Msamples/s", "steps": steps,
+           "ms_per_step": round(elapsed / steps * 1e3, 5), "calls_chained": batch.chained_calls - before}
+    batch.close()
+    del src, dst
+    import torch
+    torch.cuda.empty_cache()
+    return out
+
+
 def config5_leg(rank, world, local_rank, steps, sharding, backend):
     """One GPU's share of BASELINE.json configs[4] (262144 EAX reverbs over 8 GPUs = 32768 per GPU, 28.75 GiB of delay lines each),
     timed like the main region."""
@@ -671,8 +703,13 @@ def config5_leg(rank, world, local_rank, steps, sharding, backend):
     batch.synchronize()
     for k in range(16):
         batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
-    batch.kernel_timing(TIMED_EVERY)
     elapsed = timed_region(batch, src, dst, n_in, 32, steps, sharding, backend)
+    # the kernel by itself: a region of its own behind the timed one (launches that carry events do not overlap with their neighbours,
+    # so the timed region above, whose calls chain, carries none)
+    batch.kernel_timing(TIMED_EVERY)
+    for k in range(max(2 * TIMED_EVERY, min(steps, 40))):
+        batch.mix_device(FRAMES, src[k % n_in].data_ptr(), dst.data_ptr())
+    batch.synchronize()
     launches, ms = batch.kernel_timing_read(desc.EAX_REVERB)
     batch.kernel_timing(0)
     bracket_us = batch.event_overhead(100)
