@@ -953,7 +953,11 @@ def test_ring_light_effects_alone_stay_in_stream_order():
         assert b.chained_calls == 0
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_SEEDS", "6")))))
+_OTHER_FIRST = int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_FIRST", "0"))
+_OTHER_COUNT = int(__import__("os").environ.get("OALSFX_CHAIN_FUZZ_SEEDS", "6"))
+
+
+@pytest.mark.parametrize("seed", list(range(_OTHER_FIRST, _OTHER_FIRST + _OTHER_COUNT)) + ([2000, 2001, 2002, 2003] if _OTHER_FIRST == 0 and _OTHER_COUNT <= 6 else []))
 def test_random_runs_of_the_other_shapes(seed):
     """Random batches of the shapes whose steps chain since round 4 -- reverb-free slots in front of a reverb slot (two launches per step),
     one slot of ring-light effects and reverbs (the mixed grid), ring-light effects alone (test switch) -- with 6 to 128 instances (few
@@ -967,6 +971,9 @@ def test_random_runs_of_the_other_shapes(seed):
     n = rng.choice([6, 8, 24, 30, 70, 72, 127, 128])
     shape = rng.choice(["two launches", "two launches", "mixed grid", "mixed grid", "ring-light"])
     slots = rng.choice([2, 3, 4]) if shape == "two launches" else rng.choice([1, 1, 3]) if shape == "ring-light" else 1
+    # (other sampling rates from seed 2000 on -- every delay line changes size, low rates put the reverbs on the short-tap builds; the
+    # seeds below keep the rate they were first run with)
+    rate = 48000 if seed < 2000 else rng.choice([8000, 11025, 22050, 44100, 48000, 96000])
 
     def an_effect(slot, i):
         if shape == "two launches" and slot == slots - 1:
@@ -976,7 +983,7 @@ def test_random_runs_of_the_other_shapes(seed):
         return random_effect(rng, LIGHT_TYPES[rng.randrange(len(LIGHT_TYPES))])
 
     def body():
-        with Batch(n, fmt, 48000, slots) as b:
+        with Batch(n, fmt, rate, slots) as b:
             for s in range(slots):
                 b.set_effect(s, [an_effect(s, i) for i in range(n)])
             b.apply_changes()
@@ -1010,10 +1017,10 @@ def test_random_runs_of_the_other_shapes(seed):
             run_device_calls(b, script, shadows, 78000 + 100 * seed, replicas=False)
             # (a batch may legitimately chain nothing: a reverb that stays outside the steady-state builds, a change before every call)
             h1, d1 = b.chain_started()
-            assert h1 == d1, f"seed {seed} ({shape}, {slots} slots, {n} instances): host {h1} and device {d1} disagree"
+            assert h1 == d1, f"seed {seed} ({shape}, {slots} slots, {n} instances, {rate} Hz): host {h1} and device {d1} disagree"
             for i, s in shadows.items():
                 d = s.compare_state()
-                assert not d, f"seed {seed} ({shape}, {slots} slots, {n} instances), instance {i}: " + "; ".join(d[:4])
+                assert not d, f"seed {seed} ({shape}, {slots} slots, {n} instances, {rate} Hz), instance {i}: " + "; ".join(d[:4])
 
     _with_debug_flags(CHAIN_RING_LIGHT, body)
 
