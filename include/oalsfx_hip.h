@@ -82,7 +82,8 @@ int oalsfx_batch_mix_gather(oalsfx_batch* b, int frames, const float* const* src
  * NULL for the batch's own stream) and returns without synchronising.
  * With hip_stream NULL the call is complete when oalsfx_batch_synchronize (or any other call on the batch that waits or reads back)
  * returns; consecutive such calls may overlap on the device where the instances allow it (a step that is one steady-state reverb
- * launch: each instance of the later call starts when the earlier call is through with that instance), which takes the launch gap
+ * launch, a launch of reverb-free slots followed by one of the reverbs' slot, or one grid of ring-light effects and proven reverbs:
+ * each instance of the later call starts when the earlier call is through with that instance), which takes the launch gap
  * between dependent kernels out of a streaming loop.  A caller that wants the launches in the order of a stream it can queue its
  * own work on passes that stream, or asks for the batch's with oalsfx_batch_stream, which switches the overlap off. */
 int oalsfx_batch_mix_device(oalsfx_batch* b, int frames, const float* src_dev, float* dst_dev, void* hip_stream);
