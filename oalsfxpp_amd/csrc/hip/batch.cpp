@@ -1390,10 +1390,6 @@ bool chain_join(oalsfx_batch* b)
     return true;
 }
 
-// Can this call be a chained launch?  The batch's own stream, nobody holding its handle, no per-launch events, one chunk of whole tiles,
-// and a step that is exactly one steady-state launch.  (Any number of workgroups: the gate in front of a launch sees to it that all but
-// a few workgroups of the launch before have started, however many rounds of the chip that launch takes -- 32 768 instances, eight
-// rounds: 380 -> 360 us per step.)
 // Is this process run under a tool that collects hardware counters per kernel (rocprofv3 --pmc, or a counter file)?  Such a tool runs
 // one kernel at a time, and not in the order the queues were fed: the gate in front of a chained launch then waits for a launch the tool
 // holds back until the gate has finished -- every gate counts out (1.3 s each; measured: bench.py under `rocprofv3 --pmc SQ_WAVES`
@@ -1410,6 +1406,11 @@ bool kernels_serialised_by_a_tool()
     return yes;
 }
 
+// Can this call be a run of chained launches?  The batch's own stream, nobody holding its handle, no per-launch events, one chunk, and a
+// step of one of the shapes whose kernels take turns: one steady-state reverb launch (whole tiles, or the proven ragged builds); the
+// reverb-free slots' launch followed by the reverbs' (several slots); one grid of ring-light effects and proven reverbs.  (Any number of
+// workgroups: the gate in front of a launch sees to it that all but a few workgroups of the launch before have started, however many
+// rounds of the chip that launch takes -- 32 768 instances, eight rounds: 380 -> 360 us per step.)
 bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream, bool uploading)
 {
     if (kernels_serialised_by_a_tool()) return false;
