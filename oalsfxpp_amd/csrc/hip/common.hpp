@@ -211,7 +211,7 @@ template <class K> inline int declared_lds(K kernel)
         int more_lds_ = 0;                                                                                       \
         if (oalsfx_hip::lds_per_workgroup() > 0) {                                                               \
             static const int declared_ = oalsfx_hip::declared_lds(kernel);                                       \
-            more_lds_ = oalsfx_hip::lds_per_workgroup() > declared_ ? oalsfx_hip::lds_per_workgroup() - declared_ : 0; \
+            more_lds_ = (declared_ > 0 && oalsfx_hip::lds_per_workgroup() > declared_) ? oalsfx_hip::lds_per_workgroup() - declared_ : 0; /* (0: the runtime did not say) */ \
         }                                                                                                        \
         hipLaunchKernelGGL(kernel, grid, block, more_lds_, stream, __VA_ARGS__);                                 \
     } while (0)
