@@ -137,6 +137,9 @@ __device__ __forceinline__ void st(GlobalBytes* slab, unsigned byte_off, float v
 // requested a tile ahead: so every tap of such an instance must be three tiles away (kPlainMinTap, which host and device share).
 // Measured (scripts/ab_libs.py, profiles/r03g_aligned_windows/): 256-frame calls 43.9 -> 42.3 us (-3.5 %), 512-frame calls -8.5 %,
 // 2048-frame calls 333.8 -> 297.6 us (-10.9 %: 37.2 us per 256 frames, 0.73 of the roofline).
+#ifndef OALSFX_ABLATE_VALU
+#define OALSFX_ABLATE_VALU 0
+#endif
 #ifndef OALSFX_CHAIN_EXP
 #define OALSFX_CHAIN_EXP 0 // experiments: 1 an agent-scope acquire behind every wait for a turn, 2 plain stores of the output frames (timing only),
                            // 4 the word as an agent-scope release store (an L2 write-back in front of it),
@@ -1561,6 +1564,20 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
         stamp();
         lds_barrier();
         stamp();
+#if OALSFX_ABLATE_VALU > 0
+        // (ablation, profiles/r04c_instruction_diet/valu_ablation.txt: this many more vector instructions per wavefront and tile, doing
+        // nothing -- does the step get longer by what they take to issue?)
+        {
+            // (eight independent registers in turn: issue slots, not a chain of latencies)
+            float j0 = static_cast<float>(lane), j1 = j0 + 1.0F, j2 = j0 + 2.0F, j3 = j0 + 3.0F, j4 = j0 + 4.0F, j5 = j0 + 5.0F, j6 = j0 + 6.0F, j7 = j0 + 7.0F;
+#pragma unroll
+            for (int k = 0; k < OALSFX_ABLATE_VALU / 8; ++k)
+                asm volatile("v_mul_f32 %0, %0, %0\n\tv_mul_f32 %1, %1, %1\n\tv_mul_f32 %2, %2, %2\n\tv_mul_f32 %3, %3, %3\n\t"
+                             "v_mul_f32 %4, %4, %4\n\tv_mul_f32 %5, %5, %5\n\tv_mul_f32 %6, %6, %6\n\tv_mul_f32 %7, %7, %7"
+                             : "+v"(j0), "+v"(j1), "+v"(j2), "+v"(j3), "+v"(j4), "+v"(j5), "+v"(j6), "+v"(j7));
+            if (j0 + j1 + j2 + j3 + j4 + j5 + j6 + j7 == 12345.678F && ctx.timeline) ctx.timeline[1] = 1;
+        }
+#endif
         // ---------------- S3: P2(ta), feed-forward half of the second shelf; P4(tb), second T60 feed-forward ----------------
         if (go && has_a) {
             issue_taps_c(static_cast<unsigned>(offset + pos_a) << 2, tapbase(ta));
