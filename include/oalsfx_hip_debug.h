@@ -69,6 +69,11 @@ int oalsfx_debug_stream_pattern(int device_id, int instances, int dwords_per_lan
  * in either form (microseconds; 0 where no probe ran: the form was known for the device, or fixed by OALSFX_HOST_PIPELINE). */
 int oalsfx_debug_host_pipeline(oalsfx_batch* b, int* form, double* probe_us_three_streams, double* probe_us_one_stream);
 
+/* Test hook: every gate in front of a chained launch waits for `skew` more workgroups than will ever start, so that it gives up
+ * (after its full wait, about a second) -- what a tool that runs kernels one at a time out of queue order does to it.  The results stay
+ * whole; the batch notices at its next synchronising call and stays in stream order from then on (oalsfx_debug_chain_given_up). */
+void oalsfx_debug_gate_skew(oalsfx_batch* b, unsigned skew);
+int oalsfx_debug_chain_given_up(const oalsfx_batch* b);
 /* Chained launches: the gate in front of a launch is set by the host's count of the workgroups started so far, which every
  * workgroup of a chained launch adds itself to on the device.  Reads both (waits for the batch): the two must agree after any run. */
 int oalsfx_debug_chain_started(oalsfx_batch* b, unsigned* host_total, unsigned* device_total);

@@ -128,7 +128,9 @@ struct oalsfx_batch {
     char fault_text[400] = {};
     long long host_prepare_ns = 0, host_stage_wait_ns = 0, host_derive_ns = 0, host_lists_ns = 0; // OALSFX_HOST_PROFILE: where the host's time inside mix_device goes
     unsigned* h_fault = nullptr;                  // pinned, device-visible: instances a proven-steady launch had to leave alone (must stay 0)
-    unsigned* d_fault = nullptr;                  // device address of h_fault
+    unsigned* d_fault = nullptr;                  // device address of h_fault  ([1]: gates of chained launches that gave up waiting, a word of its own)
+    bool chain_given_up = false;                  // gates counted out and nothing else did: something runs the queues' kernels one at a time; stream order from then on
+    uint32_t gate_skew = 0;                       // test hook (oalsfx_debug_gate_skew): added to every gate's target, so that the gates count out
     hipEvent_t ev_exact = nullptr;
     // Per slot the list is: ring-light types in ascending order (list_offset / list_count per type), then the reverb instances
     // proven steady (reverb, EAX reverb: steady_offset / fast_count), those believed steady (reverb, EAX reverb: slow_count), then
@@ -1330,11 +1332,25 @@ void poll_exact(oalsfx_batch* b)
 // unprocessed).  The host's bookkeeping makes that impossible; if it happens anyway it must not pass silently.
 bool check_fault(oalsfx_batch* b)
 {
-    if (!b->h_fault || *b->h_fault == 0) return true;
-    const unsigned f = *b->h_fault;
+    if (!b->h_fault || (b->h_fault[0] == 0 && b->h_fault[1] == 0)) return true;
+    const unsigned f = b->h_fault[0], gates = b->h_fault[1] / oalsfx_hip::kFaultGate;
+    if (f == 0) {
+        // Gates gave up waiting and nothing else went wrong: every launch behind them found its instances' turns (else the word above would
+        // say so), the results are whole.  Something holds launches of one queue back until kernels of another have finished -- a tool
+        // that runs kernels one at a time out of queue order -- and every gate costs its full wait (1.3 s).  The batch goes on in plain
+        // stream order from here, and says so once.
+        b->h_fault[1] = 0;
+        if (!b->chain_given_up) {
+            b->chain_given_up = true;
+            std::fprintf(stderr, "oalsfx: %u gate(s) of chained launches gave up waiting although no launch was held up by it: the device runs this "
+                                 "process's kernels one at a time and out of queue order (a profiler collecting counters?).  Calls of this batch "
+                                 "stay in stream order from here on (OALSFX_DEBUG_FLAGS=0x400 does that from the start).\n", gates);
+        }
+        return true;
+    }
     if (f >= oalsfx_hip::kFaultTurn) {
-        std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady; gates alone: something ran the queues' kernels one at a time and out of order -- OALSFX_DEBUG_FLAGS=0x400 gives plain stream order).",
-                      f, (f / oalsfx_hip::kFaultTurn) & 0xFFFu, f / oalsfx_hip::kFaultGate, f & 0xFFFu);
+        std::snprintf(b->fault_text, sizeof(b->fault_text), "Internal error: a chained launch gave up waiting (fault word 0x%x: %u turns, %u gates, %u instances not steady).",
+                      f, (f / oalsfx_hip::kFaultTurn) & 0xFFFu, f / oalsfx_hip::kFaultGate + gates, f & 0xFFFu);
         // (the instances concerned were left alone, and so were the launches behind them in the run: the batch's state is a buffer short
         // there.  No further call pretends otherwise.)
         b->poisoned = true;
@@ -1413,7 +1429,7 @@ bool kernels_serialised_by_a_tool()
 // rounds of the chip that launch takes -- 32 768 instances, eight rounds: 380 -> 360 us per step.)
 bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* dst, hipStream_t stream, bool uploading)
 {
-    if (kernels_serialised_by_a_tool()) return false;
+    if (kernels_serialised_by_a_tool() || b->chain_given_up) return false;
     if (b->chain_open && b->chain_dsts.size() >= 256) {
         // (a caller that hands in a fresh output buffer with every call: the list of a run's output buffers starts over with a new run)
         const char* lo = reinterpret_cast<const char*>(dst);
@@ -1540,8 +1556,8 @@ bool chain_next_launch(oalsfx_batch* b, KernelCtx& ctx, int depth, PendingUpload
         // tests/test_gpu_chained.py::test_the_first_run_of_a_fresh_process)
         if (b->chain_len == 2 || !(debug_flags() & 0x800)) {
             const unsigned target = b->started_total - static_cast<uint32_t>(std::min(8, (b->n + 3) / 4 - 1));
-            if (upload && upload->st) { upload->jobs.gate_started = started; upload->jobs.gate_target = target; } // (the upload kernel is the gate as well)
-            else oalsfx_hip::launch_chain_gate(started, target, b->d_fault, stream);
+            if (upload && upload->st) { upload->jobs.gate_started = started; upload->jobs.gate_target = target + b->gate_skew; } // (the upload kernel is the gate as well)
+            else oalsfx_hip::launch_chain_gate(started, target + b->gate_skew, b->d_fault + 1, stream);
         }
     }
     ctx.turn_started = started;
@@ -1891,8 +1907,8 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     ok = ok && b->hip_ok(handed_on_malloc(b, reinterpret_cast<void**>(&b->d_exact), total * sizeof(unsigned)), "hipMalloc(exact)");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_exact, 0, total * sizeof(unsigned), b->stream), "hipMemsetAsync(exact)");
     ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_exact), total * sizeof(unsigned)), "hipHostMalloc(exact)");
-    ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_fault), sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(fault)");
-    if (ok) *b->h_fault = 0;
+    ok = ok && b->hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b->h_fault), 2 * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(fault)");
+    if (ok) b->h_fault[0] = b->h_fault[1] = 0;
     ok = ok && b->hip_ok(hipHostGetDevicePointer(reinterpret_cast<void**>(&b->d_fault), b->h_fault, 0), "hipHostGetDevicePointer");
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_exact, hipEventDisableTiming), "hipEventCreate");
     ok = ok && b->hip_ok(hipMemsetAsync(b->d_state, 0, total * sizeof(oalsfx_hip::SlotStateLines), b->stream), "hipMemsetAsync(state)");
@@ -2473,6 +2489,9 @@ unsigned long long oalsfx_trim_pools(void)
 }
 
 unsigned long long oalsfx_pools_waiting_bytes(void) { return uncached_pool().bytes_waiting(); }
+
+void oalsfx_debug_gate_skew(oalsfx_batch* b, unsigned skew) { if (b) b->gate_skew = skew; }
+int oalsfx_debug_chain_given_up(const oalsfx_batch* b) { return b && b->chain_given_up ? 1 : 0; }
 
 int oalsfx_debug_chain_started(oalsfx_batch* b, unsigned* host_total, unsigned* device_total)
 {

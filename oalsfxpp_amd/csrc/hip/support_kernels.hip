@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_upload(UploadJobs jobs)
     int k = blockIdx.x;
     const int t = threadIdx.x;
     // (the gate of the chained launch behind this upload: one wavefront's worth of waiting, beside the work of the others)
-    if (blockIdx.x == 0 && t == 255 && jobs.gate_started != nullptr) chain_gate_wait(jobs.gate_started, jobs.gate_target, jobs.fault);
+    if (blockIdx.x == 0 && t == 255 && jobs.gate_started != nullptr) chain_gate_wait(jobs.gate_started, jobs.gate_target, jobs.fault ? jobs.fault + 1 : nullptr); // (gates that give up count in the word behind the fault word)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const ScatterJob& sj = jobs.scatter[j];

@@ -75,6 +75,8 @@ SIGNATURES = {
     "oalsfx_pools_waiting_bytes": (C.c_ulonglong, []),
     "oalsfx_debug_chain_same_cu": (C.c_longlong, [C.c_void_p]),
     "oalsfx_debug_chain_started": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    "oalsfx_debug_gate_skew": (None, [C.c_void_p, C.c_uint]),
+    "oalsfx_debug_chain_given_up": (C.c_int, [C.c_void_p]),
     "oalsfx_debug_host_pipeline": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "oalsfx_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "oalsfx_debug_set_flags": (None, [C.c_int]),

@@ -1079,3 +1079,35 @@ def test_every_instance_of_configs_3_through_consecutive_chained_calls():
             assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
         # (random properties: a reverb that stays outside the steady-state builds would keep the step in stream order -- none does today)
         assert chained == calls, chained
+
+
+def test_gates_that_give_up_leave_the_results_whole_and_the_batch_in_stream_order():
+    """What a tool that runs kernels one at a time out of queue order does to a run of chained launches: every gate waits for workgroups
+    the tool holds back, and gives up.  Forced here by a gate target no launch reaches (oalsfx_debug_gate_skew).  Nothing else went wrong --
+    every launch found its instances' turns -- so the results must be whole, the synchronising call must not fail, and the batch must
+    stay in stream order from then on."""
+    so = lib.load()
+    n = 72
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        b.set_effect(0, [preset_effect((3 * i) % 113) for i in range(n)])
+        b.apply_changes()
+        shadows = {i: OracleShadow(b, i) for i in (0, 1, 17, 35, 70, 71)}
+        for s in shadows.values():
+            s.sync()
+        warm = np.zeros((n, 256, 2), dtype=np.float32)
+        for _ in range(3):
+            b.mix(warm)
+            for s in shadows.values():
+                s.oracle.mix(warm[0])
+        so.oalsfx_debug_gate_skew(b._h, 100000)
+        before = b.chained_calls
+        run_device_calls(b, [256] * 3, shadows, 61000)          # two gates, each its full wait
+        assert b.chained_calls - before == 3
+        assert so.oalsfx_debug_chain_given_up(b._h) == 1
+        so.oalsfx_debug_gate_skew(b._h, 0)
+        before = b.chained_calls
+        run_device_calls(b, [256] * 6, shadows, 62000)
+        assert b.chained_calls == before                          # stream order from here on
+        for i, s in shadows.items():
+            d = s.compare_state()
+            assert not d, f"instance {i}: " + "; ".join(d[:12])
