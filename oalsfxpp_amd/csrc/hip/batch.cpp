@@ -1417,6 +1417,7 @@ bool kernels_serialised_by_a_tool()
         const char* on = std::getenv("ROCPROF_COUNTER_COLLECTION");   // rocprofv3 --pmc / -i: "1"
         const char* which = std::getenv("ROCPROF_COUNTERS");          // ... and the counters asked for
         const char* v1 = std::getenv("ROCP_METRICS");                 // rocprof (v1) with an input file
+        if (std::getenv("OALSFX_IGNORE_TOOLS")) return false;         // (tests of what happens under a tool this does not recognise)
         return (on && std::atoi(on) != 0) || (which && *which) || (v1 && *v1);
     }();
     return yes;

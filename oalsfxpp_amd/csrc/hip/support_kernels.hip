@@ -261,13 +261,19 @@ __global__ __launch_bounds__(256) void k_send_filters(KernelCtx ctx, const float
 // Chained launches (batch.cpp): a launch whose workgroups wait for the launch before must not take the chip before that
 // launch has its workgroups on it; every chained launch but a run's first comes behind this gate.  (In the steady state of a run it
 // finds its count reached: the launch before has been taking over the places of the launch two before, which has just completed.)
+// (A gate that gives up leaves a mark beside the count, started[2], and the gates behind it do not wait at all: whatever held the launch
+// before back -- a tool that runs kernels one at a time out of queue order -- will hold the next one back as well, and a second apiece
+// adds up, a run of a thousand calls before the host next looks.  The host turns chaining off for the batch when it does: check_fault.)
 __device__ __forceinline__ void chain_gate_wait(const unsigned* started, unsigned target, unsigned* fault)
 {
+    unsigned* gave_up = const_cast<unsigned*>(started) + 2;
+    if (__hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     unsigned spins = 0;
     while (static_cast<int>(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 22)) {
             if (fault) __hip_atomic_fetch_add(fault, kFaultGate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
