@@ -1054,8 +1054,8 @@ bool ensure_mixbuf(oalsfx_batch* b)
 // workgroups; measured slower: chain_eligible), 0x2000 no proven ragged builds (calls that end in a partial tile on the believing build, in stream
 // order: as before round 4), 0x4000 no line-aligned store build for write positions off the line grid (reverb.hip, CR == 2: as
 // before round 4), 0x800 the gate of chained launches in front of a run's second launch only (a negative control
-// of tests/test_gpu_chained.py: it must fail), 0x40000 no chained steps of two launches (batches of several slots in stream order, as
-// before round 4), 0x10 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
+// of tests/test_gpu_chained.py: it must fail), 0x40000 none of the shapes that chain since late round 4 (steps of two launches, the mixed grid, more than two channels: stream
+// order as before), 0x10 a chained step's ring-light launch in its own list order instead of the reverbs' grid's (experiment),
 // 0x80 batches without any reverb chain their calls too (tests of the ring-light kernel's hand-over; measured slower: chain_eligible),
 // 0x1000 a chained step's two kernels with the workgroup sizes they declare (experiment: the places one kernel's workgroups give up
 // do not fit the other's).  Environment beside the flags: OALSFX_RING_MEMORY=default|finegrained|uncached (where
@@ -1450,7 +1450,17 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
     if (!b->uncached) return false;
     for (const auto& kv : b->pools)
         if (kv.first % 32 != 0) return false; // (a slab of delay lines ends where its last cache line ends: reverb.hip, chained launches)
-    if (b->channels > 2 || frames > OALSFX_MAX_CHUNK) return false;
+    if (frames > OALSFX_MAX_CHUNK) return false;
+    if (b->channels > 2) {
+        // More than two channels (round 4, late): one launch of the believing build for every instance, all of them proven and at rest (no
+        // general kernel behind it); its output frames written through two channels a store.  Quad / 5.1 / 7.1, 4096 EAX reverbs:
+        // 63.6 -> 59.5, 69.9 -> 63.0, 81.2 -> 74.1 us per step (profiles/r04m_multichannel_chained/; round 3 had measured a loss, with one
+        // write-through store per channel).  0x40000: such batches in stream order as before.
+        if (debug_flags() & 0x40000) return false;
+        const int last_block = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
+        return b->slots == 1 && !uploading && (frames & 63) == 0 && b->n_filtered == 0 && b->general_count[0] == 0 && b->slow_count[0] == 0 &&
+               b->fast_count[0] == b->n && last_block / 64 >= b->rest_tiles[0] && !(debug_flags() & 0x200000);
+    }
     if (b->slots > 1) {
         // A step of two launches (round 4): every slot but the last free of reverbs for every instance -- one launch of the ring-light
         // kernel, a wavefront per instance walking its slots -- and the last slot one grid of steady-state reverbs.  Both take turns by
@@ -1876,8 +1886,7 @@ oalsfx_batch* oalsfx_batch_create(int n_instances, int channel_format, int sampl
     {
         // can a call of this batch ever be a chained launch?  (chain_eligible has the conditions that change from call to call)
         const char* kind = std::getenv("OALSFX_RING_MEMORY");
-        b->uncached = b->channels <= 2 &&
-                      (!kind || std::strcmp(kind, "uncached") == 0) && uncached_memory_available(b->device);
+        b->uncached = (!kind || std::strcmp(kind, "uncached") == 0) && uncached_memory_available(b->device);
     }
     ok = ok && b->hip_ok(hipEventCreateWithFlags(&b->ev_chain_start, hipEventDisableTiming), "hipEventCreate");
     for (int k = 0; k < kSideStreams; ++k) {

@@ -1725,6 +1725,22 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                 }
                 if (!act) {
                     // a lane past the end of a ragged call's last tile
+                } else if (last && ctx.turn_set != 0u) {
+                    // a chained launch writes the caller's frames through, as the stereo builds do (see below): two channels a store where a
+                    // frame is an even number of channels (quad, 5.1, 7.1), one apiece where it is not (6.1: seven)
+                    if ((nch & 1) == 0) {
+#pragma unroll
+                        for (int c = 0; c < 8; c += 2)
+                            if (c < nch) {
+                                const unsigned long long both = static_cast<unsigned long long>(__float_as_uint(outv[MC ? c : 0])) |
+                                                                (static_cast<unsigned long long>(__float_as_uint(outv[MC ? c + 1 : 0])) << 32);
+                                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + static_cast<size_t>(pos_b) * nch + c), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (c < nch) __hip_atomic_store(reinterpret_cast<unsigned*>(dst + static_cast<size_t>(pos_b) * nch + c), __float_as_uint(outv[MC ? c : 0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 } else if (last) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
