@@ -1154,7 +1154,8 @@ def test_chained_calls_of_more_than_two_channels_match_the_oracle(fmt):
                 s.oracle.mix(warm[0])
         before = b.chained_calls
         run_device_calls(b, [256] * 24 + [64, 128, 512, 2048, 256, 256], shadows, 63000)
-        assert b.chained_calls - before >= 24, (before, b.chained_calls)
+        # (6.1: seven channels a frame cannot be written two a store; measured slower chained, left in stream order)
+        assert (b.chained_calls - before >= 24) if fmt != desc.FMT_6POINT1 else (b.chained_calls == before), (before, b.chained_calls)
         h, d = b.chain_started()
         assert h == d
         for i, s in shadows.items():
