@@ -905,7 +905,17 @@ __device__ __forceinline__ void wave_instance(const KernelCtx& ctx, int slot, in
     };
     auto store_tile = [&](const float* o, int p, bool a) {
         if (!a) return;
-        if (last) {
+        if (last && ctx.turn_set != 0u && CH <= 2) {
+            // a chained launch (the mixed grid; ring-light batches under the test switch): the caller's buffer is ordinary memory, and two
+            // launches in flight may write the same frames from two XCDs -- written through (agent scope), so that no older line waits in
+            // another L2 to be written back over this one (the reverb groups of the grid do the same)
+            if (CH == 2) {
+                const unsigned long long both = static_cast<unsigned long long>(__float_as_uint(o[0])) | (static_cast<unsigned long long>(__float_as_uint(o[CH - 1])) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + static_cast<size_t>(p) * 2), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(reinterpret_cast<unsigned*>(dst + p), __float_as_uint(o[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (last) {
             if (CH == 2) {
                 *reinterpret_cast<float2*>(dst + static_cast<size_t>(p) * 2) = make_float2(o[0], o[CH - 1]);
             } else {

@@ -1214,3 +1214,38 @@ def test_more_than_two_channels_with_the_same_cu_path_taken_by_every_wavefront()
     # (the control that must fail -- 4 | 2 -- is left to the stereo builds: on this build it came out wrong in a run by itself and right
     # in the middle of the suite; whether the lines read early are old depends on how far the launches overlap)
     _with_debug_flags(4 | 1, run)
+
+
+def test_the_mixed_grid_many_chained_calls_into_one_buffer():
+    """BASELINE configs[3] (8192 instances, two rounds of the chip per launch), 200 calls without a synchronisation, every call into the
+    *same* output buffer: two launches in flight write the same frames from different XCDs, and the ring-light wavefronts of a chained
+    launch write them through like the reverb groups do (an older line left in another L2 would be written back over the newer frames).
+    Every instance against an oracle of its own for the last buffer, then states and delay lines of a sample."""
+    import torch
+    from harness import ShadowArmy
+    from oalsfxpp_amd.workloads import setup
+    n, frames, calls = 8192, 256, 200
+    with Batch(n, desc.FMT_STEREO, 48000, 1) as b:
+        setup(b, "config4")
+        army = ShadowArmy(b, instances=range(0, n, 7))
+        army.sync()
+        xs = [np.stack([orc.synth(66000 + i, k, frames * 2).reshape(frames, 2) for i in range(n)]) for k in range(4)]
+        for _ in range(5):
+            b.mix(xs[3])
+            army.mix(xs[3])
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = torch.empty_like(dx[0])
+        torch.cuda.synchronize()
+        before = b.chained_calls
+        for k in range(calls):
+            b.mix_device(frames, dx[k % 4].data_ptr(), dy.data_ptr())
+        b.synchronize()
+        assert b.chained_calls - before >= calls - 2, (before, b.chained_calls)
+        ref = None
+        for k in range(calls):
+            ref = army.mix(xs[k % 4])
+        bad = army.differing(dy.cpu().numpy(), ref)
+        assert not bad, f"{len(bad)} instances differ in the last buffer, the first {bad[:6]}"
+        for s in army.shadows[::97]:
+            d = s.compare_state()
+            assert not d, f"instance {s.instance}: " + "; ".join(d[:12])
