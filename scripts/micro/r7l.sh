@@ -1,4 +1,4 @@
-# more than two channels chained (OALSFX_CHAIN_MC=1, experiment) against stream order: quad / 5.1 / 7.1, 4096 EAX reverbs, 256-frame calls
+# more than two channels chained against stream order as first measured (OALSFX_CHAIN_MC was the experiment's switch; chaining is the default since, OALSFX_DEBUG_FLAGS=0x40000 the way back): quad / 5.1 / 7.1, 4096 EAX reverbs, 256-frame calls
 mkdir -p gpurun_out/r7l
 cat > /tmp/mc_probe.py <<'PY'
 import sys, time
