@@ -1456,9 +1456,9 @@ bool chain_eligible(oalsfx_batch* b, int frames, const float* src, const float* 
         // general kernel behind it); its output frames written through two channels a store.  Quad / 5.1 / 7.1, 4096 EAX reverbs:
         // 63.6 -> 59.5, 69.9 -> 63.0, 81.2 -> 74.1 us per step (profiles/r04m_multichannel_chained/; round 3 had measured a loss, with one
         // write-through store per channel).  0x40000: such batches in stream order as before.
-        // (6.1, seven channels a frame, cannot pair them: one write-through store apiece, 74.6 -> 86.5 us per step chained -- what round 3 saw.
-        // It stays in stream order.)
-        if ((debug_flags() & 0x40000) || (b->channels & 1)) return false;
+        // (6.1, seven channels a frame: one write-through store per channel made it 74.6 -> 86.5 us per step chained -- what round 3 saw; its
+        // pairs now start where the frame's parity puts an even float, three pairs and one channel alone: 75.3-76.7 -> 73.1-73.2.)
+        if (debug_flags() & 0x40000) return false;
         const int last_block = frames - ((frames - 1) / OALSFX_RV_MAX_UPDATE) * OALSFX_RV_MAX_UPDATE;
         return b->slots == 1 && !uploading && (frames & 63) == 0 && b->n_filtered == 0 && b->general_count[0] == 0 && b->slow_count[0] == 0 &&
                b->fast_count[0] == b->n && last_block / 64 >= b->rest_tiles[0] && !(debug_flags() & 0x200000);

@@ -1727,8 +1727,8 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                     // a lane past the end of a ragged call's last tile
                 } else if (last && ctx.turn_set != 0u) {
                     // a chained launch writes the caller's frames through, as the stereo builds do (see below): two channels a store where a
-                    // frame is an even number of channels (quad, 5.1, 7.1); one apiece where it is not (6.1: seven -- measured slower than stream
-                    // order, 86.5 against 74.6 us per step, so the host does not chain such batches: chain_eligible)
+                    // frame is an even number of channels (quad, 5.1, 7.1); 6.1's seven below (one store apiece measured slower than stream order,
+                    // 86.5 against 74.6 us per step)
                     if ((nch & 1) == 0) {
 #pragma unroll
                         for (int c = 0; c < 8; c += 2)
@@ -1738,9 +1738,27 @@ __device__ __forceinline__ void reverb_steady_group(const KernelCtx& ctx, int sl
                                 __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + static_cast<size_t>(pos_b) * nch + c), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                     } else {
+                        // an odd number of channels (6.1: seven): a pair must start at an even float, which depends on the frame's parity -- an
+                        // even frame stores (0,1) (2,3) (4,5) and its last channel alone, an odd one its first channel alone and (1,2) (3,4) (5,6)
+                        const bool odd = (pos_b & 1) != 0;
+                        float* frame = dst + static_cast<size_t>(pos_b) * nch;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            if (c < nch) __hip_atomic_store(reinterpret_cast<unsigned*>(dst + static_cast<size_t>(pos_b) * nch + c), __float_as_uint(outv[MC ? c : 0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k = 0; k < 3; ++k) {
+                            const float lo = odd ? outv[MC ? 2 * k + 1 : 0] : outv[MC ? 2 * k : 0];
+                            const float hi = odd ? outv[MC ? 2 * k + 2 : 0] : outv[MC ? 2 * k + 1 : 0];
+                            const int at = 2 * k + (odd ? 1 : 0);
+                            if (at + 1 < nch) {
+                                const unsigned long long both = static_cast<unsigned long long>(__float_as_uint(lo)) | (static_cast<unsigned long long>(__float_as_uint(hi)) << 32);
+                                __hip_atomic_store(reinterpret_cast<unsigned long long*>(frame + at), both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        // (nch is 7 here -- the only odd count above two -- but written for any: the channel no pair took)
+                        const int alone = odd ? 0 : nch - 1;
+                        float v = outv[0];
+#pragma unroll
+                        for (int c = 1; c < 8; ++c)
+                            if (MC && c == alone) v = outv[MC ? c : 0];
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(frame + alone), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 } else if (last) {
 #pragma unroll

@@ -1138,8 +1138,8 @@ def test_gates_that_give_up_leave_the_results_whole_and_the_batch_in_stream_orde
 @pytest.mark.parametrize("fmt", [desc.FMT_QUAD, desc.FMT_5POINT1, desc.FMT_5POINT1_REAR, desc.FMT_6POINT1, desc.FMT_7POINT1])
 def test_chained_calls_of_more_than_two_channels_match_the_oracle(fmt):
     """Quad, 5.1, 5.1 rear, 6.1 and 7.1 outputs: one launch of the believing build per call once every instance is proven, consecutive
-    calls overlapping like the stereo ones; the caller's frames written through two channels a store (6.1, seven channels a frame: one
-    apiece).  72 reverbs of many presets, calls of 64 to 2048 frames."""
+    calls overlapping like the stereo ones; the caller's frames written through two channels a store (6.1, seven channels a frame:
+    three pairs that start where the frame's parity puts an even float, and one channel alone).  72 reverbs of many presets, calls of 64 to 2048 frames."""
     n = 72
     with Batch(n, fmt, 48000, 1) as b:
         b.set_effect(0, [preset_effect((3 * i) % 113, desc.EAX_REVERB if i % 4 else desc.REVERB) for i in range(n)])
@@ -1154,8 +1154,7 @@ def test_chained_calls_of_more_than_two_channels_match_the_oracle(fmt):
                 s.oracle.mix(warm[0])
         before = b.chained_calls
         run_device_calls(b, [256] * 24 + [64, 128, 512, 2048, 256, 256], shadows, 63000)
-        # (6.1: seven channels a frame cannot be written two a store; measured slower chained, left in stream order)
-        assert (b.chained_calls - before >= 24) if fmt != desc.FMT_6POINT1 else (b.chained_calls == before), (before, b.chained_calls)
+        assert b.chained_calls - before >= 24, (before, b.chained_calls)
         h, d = b.chain_started()
         assert h == d
         for i, s in shadows.items():
