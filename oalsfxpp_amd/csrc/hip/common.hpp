@@ -216,7 +216,8 @@ template <class K> inline int declared_lds(K kernel)
         hipLaunchKernelGGL(kernel, grid, block, more_lds_, stream, __VA_ARGS__);                                 \
     } while (0)
 
-// A kernel whose wavefronts must take up exactly 128 registers, whatever the build needs (see set_lds_per_workgroup): the last statement
+// A kernel whose wavefronts must take up exactly 128 registers, whatever the build needs (see set_lds_per_workgroup; used by the variants
+// of the reverb builds that a two-kernel step launches, k_reverb_steady_coop_ep, and by the mono ring-light kernel): the last statement
 // of the kernel, where nothing is live (as the first it cost several builds a spill).
 #define OALSFX_EQUAL_PLACES() asm volatile("" ::: "v127")
 

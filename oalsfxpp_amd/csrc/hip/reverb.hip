@@ -1894,6 +1894,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop(KernelCtx ctx
 {
     __shared__ SteadyShared<CH, NW, FP, MD, ST, SF, CR> sh;
     reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
+}
+
+// The same builds taking exactly 128 registers per lane whatever they need (OALSFX_EQUAL_PLACES, common.hpp): for a chained step of two
+// different kernels (batch.cpp), whose workgroups must fit each other's places.  Not for a run of this kernel alone: with every
+// wavefront at 128 registers a full chip has none left, and the one-wavefront gate in front of the next launch (k_chain_gate) finds no
+// place until a workgroup leaves -- the headline measured 41.3 us per step that way against 40.6 with the build's own 120, the
+// driver's 20-step command 45.3 against 43.7 (profiles/r04n_places_and_the_gate/).
+template <int CH, int NW, bool TL = false, bool HY = false, bool MD = false, bool ST = false, bool RG = false, bool FP = false, bool XF = false, bool NF = false, bool SF = false, int CR = 0>
+__global__ __launch_bounds__(64 * NW, 4) void k_reverb_steady_coop_ep(KernelCtx ctx, int slot, const int* __restrict__ list, int count, int flags)
+{
+    __shared__ SteadyShared<CH, NW, FP, MD, ST, SF, CR> sh;
+    reverb_steady_group<CH, NW, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR>(ctx, slot, list, count, flags, static_cast<int>(blockIdx.x), sh);
     if constexpr (!(RG && CR == 2 && CH == 2)) OALSFX_EQUAL_PLACES(); // (that build takes 128 registers as it is, and spilled with the statement)
 }
 
@@ -2627,9 +2639,21 @@ void launch_slot_mixed(const KernelCtx& ctx, int slot, const int* steady_list, i
 // holds back every store site's tail (CR == 2) instead of the late feed's only.
 // Returns the symbol it launched (every template argument, as rocprofv3 prints them), nullptr when there was nothing to launch.
 // template arguments: channels, wavefronts per workgroup, TL, HY, MD, ST, RG, FP, XF, NF, SF, CR
+// (a chained step of two kernels -- whole tiles, proven builds only -- takes the variant whose wavefronts allocate 128 registers)
+template <int CHv, bool TLv, bool HYv, bool MDv, bool STv, bool RGv, bool FPv, bool XFv, int CRv>
+static void launch_steady_build(dim3 grid, dim3 block, hipStream_t stream, const KernelCtx& c, int slot, const int* list, int count, int flags)
+{
+    if constexpr (FPv && !RGv) {
+        if (oalsfx_hip::lds_per_workgroup() > 0) {
+            OALSFX_LAUNCH((k_reverb_steady_coop_ep<CHv, 4, TLv, HYv, MDv, STv, RGv, FPv, XFv, false, false, CRv>), grid, block, stream, c, slot, list, count, flags);
+            return;
+        }
+    }
+    OALSFX_LAUNCH((k_reverb_steady_coop<CHv, 4, TLv, HYv, MDv, STv, RGv, FPv, XFv, false, false, CRv>), grid, block, stream, c, slot, list, count, flags);
+}
 #define OALSFX_STEADY(CHv, TLv, HYv, MDv, STv, RGv, FPv, XFv, CRv)                                                                               \
     do {                                                                                                                                         \
-        OALSFX_LAUNCH((k_reverb_steady_coop<CHv, 4, TLv, HYv, MDv, STv, RGv, FPv, XFv, false, false, CRv>), grid, block, stream, c, slot, list, count, flags); \
+        launch_steady_build<CHv, TLv, HYv, MDv, STv, RGv, FPv, XFv, CRv>(grid, block, stream, c, slot, list, count, flags);                       \
         return "k_reverb_steady_coop<" #CHv ", 4, " #TLv ", " #HYv ", " #MDv ", " #STv ", " #RGv ", " #FPv ", " #XFv ", false, false, " #CRv ">";  \
     } while (0)
 const char* launch_reverb_steady(const KernelCtx& ctx, int slot, const int* list, int count, int flags, bool close_taps, bool modulated, bool short_taps,

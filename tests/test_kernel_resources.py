@@ -48,13 +48,20 @@ def test_four_workgroups_per_cu_fit():
 def test_the_kernels_of_a_chained_run_take_places_of_one_size():
     """A run of chained launches may alternate between two kernels (a step of two launches: the ring-light kernel, then the reverbs' grid):
     a CU hands out registers in contiguous blocks, and a 128-register wavefront does not fit the place a 120-register one gave up (measured:
-    113 us per step instead of 89).  Every mono / stereo build of the kernels that take turns allocates exactly 128 (OALSFX_EQUAL_PLACES);
+    113 us per step instead of 89).  The kernels such a step launches -- the reverb builds' variants k_reverb_steady_coop_ep, the grid of
+    kinds, the ring-light kernel -- allocate exactly 128 (OALSFX_EQUAL_PLACES);
     their LDS is made equal at launch time (set_lds_per_workgroup: at most 40 960 B declared, see the test above)."""
     ks = kernels()
-    grids = {k: v for k, v in ks.items() if k.startswith(("k_reverb_steady_coop<1", "k_reverb_steady_coop<2", "k_reverb_steady_kinds", "k_wave_effects<1,", "k_wave_effects<2,"))}
-    assert len(grids) >= 30, sorted(ks)
+    grids = {k: v for k, v in ks.items() if k.startswith(("k_reverb_steady_coop_ep<", "k_reverb_steady_kinds", "k_wave_effects<1,", "k_wave_effects<2,"))}
+    assert len(grids) >= 20, sorted(ks)
     for name, r in grids.items():
         assert r["vgpr"] == 128, f"{name}: {r['vgpr']} registers"
+        if name.startswith("k_reverb_steady_coop_ep<"):
+            assert r["scratch"] == 0, f"{name}: {r['scratch']} B of scratch per lane"
+    # ... and the builds a run of one kernel launches keep what they need: with every wavefront at 128 registers a full chip has none left
+    # for the one-wavefront gate in front of the next launch (the headline: 41.3 us per step that way against 40.6)
+    headline = ks["k_reverb_steady_coop<2, 4, false, false, false, false, false, true, false, false, false, 0>"]
+    assert headline["vgpr"] <= 120, headline
 
 
 def test_the_proven_builds_carry_no_scratch():
